@@ -1,0 +1,332 @@
+"""ctypes binding of the CPU oracle (oracle/liblh_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Import this from tests/, from
+``__graft_entry__.smoke()`` and from the ``cpu_baseline`` leg of ``bench.py``
+-- never from the product package ``landhydrology.jl_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblh_oracle.so")
+
+MODEL_RICHARDS, MODEL_HEAT, MODEL_COUPLED = 0, 1, 2
+BC_NONE, BC_FLUX, BC_DIRICHLET, BC_FREE_DRAINAGE = 0, 1, 2, 3
+FACE_BOTTOM, FACE_TOP = 0, 1
+COMP_ENERGY, COMP_HYDROLOGY = 0, 1
+
+
+class EarthParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("rho_liq", "rho_ice", "cp_l", "cp_i", "T_0", "LH_f0", "K_therm")]
+
+
+class SoilParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("nu", "S_s", "nu_ss_gravel", "nu_ss_om", "nu_ss_quartz", "rho_c_ds",
+                 "kappa_solid", "rho_p", "kappa_sat_unfrozen", "kappa_sat_frozen", "a", "b",
+                 "kappa_dry_parameter")]
+
+
+class VGParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("n", "alpha", "theta_r", "Ksat")]
+
+
+class CondFactors(C.Structure):
+    _fields_ = [("viscosity_kind", C.c_int32), ("impedance_kind", C.c_int32),
+                ("gamma", C.c_double), ("T_ref", C.c_double), ("Omega", C.c_double)]
+
+
+class BC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("value", C.c_double)]
+
+
+class Model(C.Structure):
+    _fields_ = [("model", C.c_int32), ("nlev", C.c_int32), ("zmin", C.c_double),
+                ("zmax", C.c_double), ("earth", EarthParams), ("soil", SoilParams),
+                ("vg", VGParams), ("cf", CondFactors), ("bc", (BC * 2) * 2),
+                ("consistent_bottom_sign", C.c_int32), ("pad_", C.c_int32)]
+
+
+_DP = C.POINTER(C.c_double)
+
+
+class PerCol(C.Structure):
+    _fields_ = [("vg_n", _DP), ("vg_alpha", _DP), ("vg_theta_r", _DP), ("vg_Ksat", _DP),
+                ("nu", _DP), ("S_s", _DP), ("bc_value", (_DP * 2) * 2)]
+
+
+# CLIMAParameters 0.1 values (K_therm and T_0 are pinned by the
+# reference's tests, the others are unpinned and therefore inputs everywhere).
+def default_earth() -> EarthParams:
+    return EarthParams(rho_liq=1000.0, rho_ice=916.7, cp_l=4181.0, cp_i=2100.0, T_0=273.16,
+                       LH_f0=2.8344e6 - 2.5008e6, K_therm=2.4e-2)
+
+
+def default_soil(**kw) -> SoilParams:
+    """src/SoilModel/parameters.jl:11-43 defaults (loam)."""
+    d = dict(nu=0.43, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.41,
+             rho_c_ds=2700.0, kappa_solid=3.97, rho_p=2700.0, kappa_sat_unfrozen=1.72,
+             kappa_sat_frozen=3.13, a=0.24, b=18.1, kappa_dry_parameter=0.053)
+    d.update(kw)
+    return SoilParams(**d)
+
+
+def default_vg(**kw) -> VGParams:
+    """SoilWaterParameterizations.jl:161-166 defaults (loam)."""
+    d = dict(n=1.56, alpha=3.6, theta_r=0.0, Ksat=2.9e-7)
+    d.update(kw)
+    return VGParams(**d)
+
+
+def default_cf(viscosity=False, impedance=False, gamma=2.64e-2, T_ref=288.0, Omega=7.0):
+    return CondFactors(int(viscosity), int(impedance), gamma, T_ref, Omega)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (building the checker is not using it)."""
+    srcs = [os.path.join(_HERE, f) for f in ("lh_oracle.c", "lh_oracle_impl.inc", "lh_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B", "liblh_oracle.so"], check=True,
+                   stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    i64 = C.c_int64
+    for sfx, ft in (("f64", C.c_double), ("f32", C.c_float)):
+        P = C.POINTER(ft)
+        vgp, ep, sp, cfp = (C.POINTER(VGParams), C.POINTER(EarthParams), C.POINTER(SoilParams),
+                            C.POINTER(CondFactors))
+
+        def sig(name, res, args):
+            f = getattr(L, f"{name}_{sfx}")
+            f.restype, f.argtypes = res, args
+
+        sig("lho_grid", None, [C.c_double, C.c_double, C.c_int, P, P])
+        sig("lho_volumetric_liquid_fraction", ft, [ft, ft])
+        sig("lho_effective_saturation", ft, [ft, ft, ft])
+        sig("lho_matric_potential", ft, [vgp, ft])
+        sig("lho_inverse_matric_potential", ft, [vgp, ft])
+        sig("lho_pressure_head", ft, [vgp, ft, ft, ft])
+        sig("lho_hydraulic_conductivity", ft, [vgp, ft, ft, ft])
+        sig("lho_viscosity_factor", ft, [cfp, ft])
+        sig("lho_impedance_factor", ft, [cfp, ft])
+        sig("lho_hydrostatic_profile", ft, [vgp, ft, ft, ft, ft])
+        sig("lho_temperature_from_rhoe_int", ft, [ft, ft, ft, ep])
+        sig("lho_volumetric_heat_capacity", ft, [ft, ft, ft, ep])
+        sig("lho_volumetric_internal_energy", ft, [ft, ft, ft, ep])
+        sig("lho_saturated_thermal_conductivity", ft, [ft, ft, ft, ft])
+        sig("lho_relative_saturation", ft, [ft, ft, ft])
+        sig("lho_kersten_number", ft, [ft, ft, sp])
+        sig("lho_thermal_conductivity", ft, [ft, ft, ft])
+        sig("lho_volumetric_internal_energy_liq", ft, [ft, ep])
+        sig("lho_k_solid", ft, [ft, ft, ft, ft, ft])
+        sig("lho_ksat_frozen", ft, [ft, ft, ft])
+        sig("lho_ksat_unfrozen", ft, [ft, ft, ft])
+        sig("lho_k_dry", ft, [ep, sp])
+        mp, pcp = C.POINTER(Model), C.POINTER(PerCol)
+        sig("lho_rhs", C.c_int, [mp, pcp, i64, P, P, P, P, P, P, P, i64, i64, C.c_int])
+        sig("lho_diagnostics", C.c_int, [mp, pcp, i64, P, P, P, P, P, P, P, P, i64, i64])
+        sig("lho_ssprk33", C.c_int, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double, C.c_double,
+                                     i64, _DP, C.c_int])
+        sig("lho_stable_dt", C.c_double, [mp, pcp, i64, P, P, P, i64, i64, C.c_double])
+    L.lho_openmp_max_threads.restype = C.c_int
+
+
+def _sfx(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64"
+    if dtype == np.float32:
+        return "f32"
+    raise TypeError(f"oracle supports float32/float64, not {dtype}")
+
+
+def fn(name: str, dtype):
+    return getattr(lib(), f"{name}_{_sfx(dtype)}")
+
+
+@dataclass
+class OracleModel:
+    """A soil model description for the oracle: everything SoilModel(...) holds
+    (src/SoilModel/models.jl:90-135) as plain numbers."""
+    model: int
+    nlev: int
+    zmin: float
+    zmax: float
+    earth: EarthParams = field(default_factory=default_earth)
+    soil: SoilParams = field(default_factory=default_soil)
+    vg: VGParams = field(default_factory=default_vg)
+    cf: CondFactors = field(default_factory=default_cf)
+    # bc[(face, comp)] = (kind, value)
+    bc: dict = field(default_factory=dict)
+    consistent_bottom_sign: bool = False
+    # per-column overrides: name -> float64 array [ncols]; bc values via
+    # percol_bc[(face, comp)]
+    percol: dict = field(default_factory=dict)
+    percol_bc: dict = field(default_factory=dict)
+
+    def c_model(self) -> Model:
+        m = Model()
+        m.model, m.nlev, m.zmin, m.zmax = self.model, self.nlev, self.zmin, self.zmax
+        m.earth, m.soil, m.vg, m.cf = self.earth, self.soil, self.vg, self.cf
+        for f in range(2):
+            for k in range(2):
+                kind, val = self.bc.get((f, k), (BC_NONE, 0.0))
+                m.bc[f][k].kind = kind
+                m.bc[f][k].value = val
+        m.consistent_bottom_sign = int(self.consistent_bottom_sign)
+        return m
+
+    def c_percol(self):
+        if not self.percol and not self.percol_bc:
+            return None, []
+        keep = []
+        pc = PerCol()
+        for name in ("vg_n", "vg_alpha", "vg_theta_r", "vg_Ksat", "nu", "S_s"):
+            if name in self.percol:
+                a = np.ascontiguousarray(self.percol[name], dtype=np.float64)
+                keep.append(a)
+                setattr(pc, name, a.ctypes.data_as(_DP))
+        for (f, k), v in self.percol_bc.items():
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append(a)
+            pc.bc_value[f][k] = a.ctypes.data_as(_DP)
+        return pc, keep
+
+
+def _ptr(a: Optional[np.ndarray], ft):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ft))
+
+
+def _ft(dtype):
+    return C.c_double if np.dtype(dtype) == np.float64 else C.c_float
+
+
+def _strides(a: np.ndarray):
+    """Arrays are [ncols, nlev] (level-fastest, like parent(field)) or any
+    2-D strided view; returns element strides (lev, col)."""
+    assert a.ndim == 2
+    it = a.itemsize
+    return a.strides[1] // it, a.strides[0] // it
+
+
+def grid(zmin, zmax, n, dtype=np.float64):
+    zc = np.empty(n, dtype=dtype)
+    zf = np.empty(n + 1, dtype=dtype)
+    ft = _ft(dtype)
+    fn("lho_grid", dtype)(zmin, zmax, n, _ptr(zc, ft), _ptr(zf, ft))
+    return zc, zf
+
+
+def rhs(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None, nthreads=1):
+    """rhs!(dY, Y, Ya, t) for a batch.  Inputs are [ncols, nlev] arrays (any
+    strides, all the same).  Returns dict of tendencies."""
+    ref = vl if vl is not None else rhoe
+    dtype = ref.dtype
+    ft = _ft(dtype)
+    ncols = ref.shape[0]
+    ls, cs = _strides(ref)
+    for a in (vl, ti, rhoe, T_aux):
+        if a is not None:
+            assert a.dtype == dtype and _strides(a) == (ls, cs) and a.shape == ref.shape
+    out = {}
+    d_vl = d_ti = d_re = None
+    if om.model != MODEL_HEAT:
+        d_vl = np.empty_like(ref)
+        d_ti = np.empty_like(ref)
+        assert _strides(d_vl) == (ls, cs)
+        out["vl"], out["ti"] = d_vl, d_ti
+    if om.model != MODEL_RICHARDS:
+        d_re = np.empty_like(ref)
+        out["rhoe"] = d_re
+    m = om.c_model()
+    pc, keep = om.c_percol()
+    rc = fn("lho_rhs", dtype)(C.byref(m), C.byref(pc) if pc is not None else None, ncols,
+                              _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft), _ptr(T_aux, ft),
+                              _ptr(d_vl, ft), _ptr(d_ti, ft), _ptr(d_re, ft), ls, cs, nthreads)
+    del keep
+    if rc:
+        raise ValueError(f"oracle rhs: invalid model/boundary combination (code {rc})")
+    return out
+
+
+def diagnostics(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None):
+    ref = vl if vl is not None else rhoe
+    dtype = ref.dtype
+    ft = _ft(dtype)
+    ls, cs = _strides(ref)
+    K, psi, T, kap = (np.empty_like(ref) for _ in range(4))
+    m = om.c_model()
+    pc, keep = om.c_percol()
+    rc = fn("lho_diagnostics", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
+                                      ref.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
+                                      _ptr(T_aux, ft), _ptr(K, ft), _ptr(psi, ft), _ptr(T, ft),
+                                      _ptr(kap, ft), ls, cs)
+    del keep
+    if rc:
+        raise ValueError(f"oracle diagnostics failed (code {rc})")
+    return dict(K=K, psi=psi, T=T, kappa=kap)
+
+
+def ssprk33(om: OracleModel, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None, t0=0.0,
+            bc_stage_values=None, nthreads=1):
+    """Advance the state arrays IN PLACE by nsteps fixed-dt SSPRK33 steps."""
+    ref = vl if vl is not None else rhoe
+    dtype = ref.dtype
+    ft = _ft(dtype)
+    ls, cs = _strides(ref)
+    bcv = None
+    if bc_stage_values is not None:
+        bcv = np.ascontiguousarray(bc_stage_values, dtype=np.float64)
+        assert bcv.shape == (nsteps, 3, 2, 2)
+    m = om.c_model()
+    pc, keep = om.c_percol()
+    rc = fn("lho_ssprk33", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
+                                  ref.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
+                                  _ptr(T_aux, ft), ls, cs, float(t0), float(dt), int(nsteps),
+                                  _ptr(bcv, C.c_double), nthreads)
+    del keep
+    if rc:
+        raise ValueError(f"oracle ssprk33 failed (code {rc})")
+
+
+def stable_dt(om: OracleModel, vl, ti, rhoe=None, courant=0.5):
+    dtype = vl.dtype
+    ft = _ft(dtype)
+    ls, cs = _strides(vl)
+    m = om.c_model()
+    pc, keep = om.c_percol()
+    r = fn("lho_stable_dt", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
+                                   vl.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft), ls, cs,
+                                   float(courant))
+    del keep
+    return r
+
+
+def max_threads() -> int:
+    return lib().lho_openmp_max_threads()
