@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- batched Richards RHS throughput on MI355X.
+
+Metric (BASELINE.json): column-cell updates/s (RHS evals).  A "step" is ONE
+lh_rhs launch over one batch: `rhs!(dY, Y, Ya, t)` for every column.  Workload at
+every N: BASELINE config C2 per GPU -- 1e6 independent 64-layer Richards columns,
+Float64, loam van Genuchten, zero-flux BCs, synthetic wetting-front state
+ -- i.e. weak scaling, columns block-partitioned over ranks, no
+data-path collective; the global stable-dt min all-reduce (RCCL) runs once per
+three RHS evals (= once per SSPRK33 step) inside the timed region when N > 1.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ncols", type=int, default=1_000_000, help="columns per GPU")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--stepper", action="store_true",
+                    help="also time the fused device SSPRK33 stepper (extra JSON field)")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name -> (case name in tests/parity_cases.py, algorithmic bytes per cell-update, dtype tag)
+    "c2": ("c2_richards_f64", 32.0, "f64"),
+    "c3": ("c3_coupled_f32", 24.0, "f32"),
+    "c4": ("c4_richards_f64_128", 32.0, "f64"),
+    "c5": ("c5_percol_f64", 32.5, "f64"),
+}
+
+
+def build_case(workload, ncols, col_offset):
+    """Synthetic inputs, generated chunk-wise on the host (counter-based hash, so
+    every rank builds exactly its own block of the global ensemble)."""
+    import parity_cases as pc
+    name = WORKLOADS[workload][0]
+    return pc.make_case(name, ncols=ncols, col_offset=col_offset)
+
+
+def cpu_baseline(case, seconds):
+    """The oracle (kind 'port': a scalar C restatement of the reference's Julia
+    path; the reference itself cannot run here) timed on a bounded sample of the
+    same workload, all host cores via OpenMP over columns."""
+    import dataclasses
+    import oracle_py as O
+    import parity_cases as pc
+    cores = os.cpu_count() or 1
+    threads = min(cores, O.max_threads())
+    n = case.om.nlev
+    sample = min(case.ncols, 20000)
+    sl = lambda a: None if a is None else np.ascontiguousarray(a[:sample])
+    om = case.om
+    if om.percol or om.percol_bc:
+        om = dataclasses.replace(om, percol={k: v[:sample] for k, v in om.percol.items()},
+                                 percol_bc={k: v[:sample] for k, v in om.percol_bc.items()})
+    sub = dataclasses.replace(case, om=om, ncols=sample, vl=sl(case.vl), ti=sl(case.ti),
+                              rhoe=sl(case.rhoe), T_aux=sl(case.T_aux))
+    pc.run_oracle_rhs(sub, nthreads=threads)            # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        pc.run_oracle_rhs(sub, nthreads=threads)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 2000:
+            break
+    return {"value": sample * n * reps / el, "unit": "cell-updates/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{reps} RHS evals of the first {sample} columns x {n} levels of the same "
+                      f"workload, OpenMP over columns on {threads} threads ({el:.1f} s)"}
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+
+    import __graft_entry__ as g
+    import parity_cases as pc
+    F = g.load_package()._ffi
+
+    case = build_case(a.workload, a.ncols, rank * a.ncols)
+    nlev = case.om.nlev
+    stream = torch.cuda.current_stream().cuda_stream
+    gm = pc.GpuModel(case, stream=stream)
+    Y, Ya = gm.prognostic_and_aux()
+    dY = gm.state(0)
+    L, ctx = gm.L, gm.ctx
+
+    # device scalar for the stable-dt min all-reduce (FT-sized, torch-owned)
+    tdt = torch.zeros(1, device="cuda", dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
+
+    def rhs_step(i):
+        F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+        if world > 1 and i % 3 == 2:     # once per SSPRK33 step
+            F.check(L.lh_stable_dt_device(ctx, Y, Ya, 0.5, tdt.data_ptr()), ctx)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MIN)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        rhs_step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(a.steps):
+        rhs_step(i)
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    assert gm.status() == 0, "non-finite tendency during the bench"
+
+    # kernel-only average duration at N = 1-style: HIP events on the launch stream
+    # around a back-to-back run of the dominant kernel alone (no collectives)
+    kreps = max(20, min(a.steps, 200))
+    torch.cuda.synchronize()
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(kreps):
+        F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+    k1.record()
+    torch.cuda.synchronize()
+    kern_ms = k0.elapsed_time(k1) / kreps
+
+    cells = a.ncols * nlev
+    bytes_per_cell = WORKLOADS[a.workload][1]
+    value = world * cells * a.steps / wall
+    achieved = cells * bytes_per_cell / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "column-cell updates/sec (RHS evals)",
+        "value": value,
+        "unit": "cell-updates/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": WORKLOADS[a.workload][2],
+        "data": "synthetic",
+        "config": {"workload": f"{a.workload.upper()}: {a.ncols} independent {nlev}-layer "
+                               f"{'coupled water+heat' if a.workload == 'c3' else 'Richards'} columns per GPU "
+                               f"({WORKLOADS[a.workload][2]}), one lh_rhs launch per step",
+                   "columns_per_gpu": a.ncols, "levels": nlev,
+                   "partition": f"block over {world} rank(s); stable-dt RCCL min all-reduce every 3rd eval"
+                   if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kern_ms, "bytes_per_cell": bytes_per_cell},
+    }
+    if a.stepper:
+        F.check(L.lh_step_ssprk33(ctx, Y, Ya, 0.0, 1e-3, 2, None), ctx)
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ns = 10
+        s0.record()
+        F.check(L.lh_step_ssprk33(ctx, Y, Ya, 0.0, 1e-3, ns, None), ctx)
+        s1.record()
+        torch.cuda.synchronize()
+        out["ssprk33_fused"] = {"ms_per_step": s0.elapsed_time(s1) / ns,
+                                "cell_updates_per_s": 3 * cells * ns / (s0.elapsed_time(s1) * 1e-3)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(case, a.cpu_seconds)
+    gm.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

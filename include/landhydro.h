@@ -1,0 +1,232 @@
+/*
+ * landhydro.h -- C ABI of liblandhydro_hip.so: the MI355X (gfx950) batched
+ * soil-column tendency path behind LandHydrology.jl's SoilModel API.
+ *
+ * What it replaces.  LandHydrology.jl has no FFI; its seam is the Julia closure
+ *     rhs!(dY, Y, Ya, t) -> dY
+ * returned by make_rhs(model::SoilModel) (src/SoilModel/right_hand_side.jl:33-44)
+ * and handed to DiffEqBase.ODEProblem (src/Simulations/simulation.jl:58-63).
+ * A Julia shim builds the same closure on top of the calls
+ * below with ccall.  Every entry point names the reference interface it stands
+ * in for (file:line under the reference tree).
+ *
+ * Conventions
+ *   - plain C types only; all entry points return 0 on success or a negative
+ *     LH_E* code, never throw; lh_last_error() gives the message (the Julia shim
+ *     turns it into error(msg), matching the reference's ArgumentError/error paths).
+ *   - a context owns ncols independent columns of nlev cells on ONE device; one
+ *     process per GPU (multi-GPU = block partition of columns over processes).
+ *   - states are device-resident and owned by the library; host pointers passed
+ *     to upload/download are borrowed for the call only.
+ *   - cells are indexed bottom -> top (test/SoilModel/coupled.jl:198); host
+ *     arrays are addressed a[col*col_stride + lev*lev_stride] (element strides),
+ *     so both parent(field)-style level-fastest columns and column-fastest
+ *     planes are accepted.
+ *   - parameters cross the ABI as double and are rounded to the working type
+ *     exactly where the Julia code applies FT(...).
+ *   - calls enqueue on the context's HIP stream; lh_download, lh_stable_dt,
+ *     lh_get_status and lh_synchronize wait for it.  A context is single-owner
+ *     (one host thread at a time), like the reference closure which mutates Ya.
+ */
+#ifndef LANDHYDRO_H
+#define LANDHYDRO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_VERSION_MAJOR 0
+#define LH_VERSION_MINOR 1
+
+/* status codes */
+enum {
+    LH_OK = 0,
+    LH_EINVAL = -1,    /* bad argument (ArgumentError in the reference) */
+    LH_ENODEVICE = -2, /* no usable HIP device / HIP runtime failure */
+    LH_ENOMEM = -3,
+    LH_EMODEL = -4, /* model / boundary-condition combination with no reference method */
+    LH_ESTATE = -5  /* state handle lacks a variable this call needs */
+};
+
+/* working type FT of SoilModel{FT} (src/SoilModel/models.jl:90-135) */
+enum { LH_F32 = 0, LH_F64 = 1 };
+
+/* which make_rhs method (right_hand_side.jl): :118-186, :192-263, :269-369 */
+enum {
+    LH_MODEL_RICHARDS = 0, /* PrescribedTemperatureModel + SoilHydrologyModel */
+    LH_MODEL_HEAT = 1,     /* SoilEnergyModel + PrescribedHydrologyModel      */
+    LH_MODEL_COUPLED = 2   /* SoilEnergyModel + SoilHydrologyModel            */
+};
+
+/* AbstractBC subtypes, src/SoilModel/boundary_conditions.jl:19-77 */
+enum { LH_BC_NONE = 0, LH_BC_FLUX = 1, LH_BC_DIRICHLET = 2, LH_BC_FREE_DRAINAGE = 3 };
+/* domain.boundary_tags, src/Domains/domain.jl:31 */
+enum { LH_FACE_BOTTOM = 0, LH_FACE_TOP = 1 };
+/* SoilComponentBC fields, boundary_conditions.jl:95-101 */
+enum { LH_COMP_ENERGY = 0, LH_COMP_HYDROLOGY = 1 };
+/* AbstractConductivityFactor, SoilWaterParameterizations.jl:38-65 */
+enum { LH_FACTOR_NONE = 0, LH_FACTOR_ON = 1 };
+
+/* variables of Y / dY / Ya (src/SoilModel/initial_conditions.jl:14-17, 85-89) */
+enum {
+    LH_VAR_VARTHETA_L = 0, /* augmented liquid fraction (Y.soil, or Ya.soil for HEAT) */
+    LH_VAR_THETA_I = 1,    /* ice fraction                                             */
+    LH_VAR_RHOE_INT = 2,   /* volumetric internal energy                               */
+    LH_VAR_T = 3,          /* Ya.soil.T (RICHARDS); diagnostics: temperature           */
+    LH_NVARS = 4
+};
+/* masks for lh_state_create */
+#define LH_MASK(var) (1u << (var))
+/* diagnostic states reuse the slots: 0 = K, 1 = psi, 2 = kappa, 3 = T */
+enum { LH_DIAG_K = 0, LH_DIAG_PSI = 1, LH_DIAG_KAPPA = 2, LH_DIAG_T = 3 };
+
+/* transcendental policy: FAST = the gfx950 log2/exp2 kernels of the product path;
+ * LIBM = ocml pow/exp (<= 1 ulp), kept for parity debugging */
+enum { LH_MATH_FAST = 0, LH_MATH_LIBM = 1 };
+
+/* per-column parameter ids for lh_set_percol_param (BASELINE config 5) */
+enum {
+    LH_PC_VG_N = 0,
+    LH_PC_VG_ALPHA = 1,
+    LH_PC_VG_THETA_R = 2,
+    LH_PC_VG_KSAT = 3,
+    LH_PC_NU = 4,
+    LH_PC_S_S = 5,
+    LH_PC_COUNT = 6
+};
+
+typedef struct lh_ctx lh_ctx;     /* one SoilModel on one device */
+typedef struct lh_state lh_state; /* one FieldVector (Y, dY or Ya) */
+
+/* Column{FT}(zlim, nelements) (src/Domains/domain.jl:12-33) x ncols, plus the
+ * SoilModel type parameters that select the method. */
+typedef struct {
+    int64_t ncols;  /* independent columns owned by this context (>= 1)       */
+    int32_t nlev;   /* Column.nelements (>= 1)                                */
+    int32_t dtype;  /* LH_F32 | LH_F64                                        */
+    double zmin;    /* Column.zlim[1]; zmin < zmax (domain.jl:30)             */
+    double zmax;    /* Column.zlim[2]                                         */
+    int32_t model;  /* LH_MODEL_*                                             */
+    int32_t device; /* HIP device ordinal; -1 = current device                */
+    void* stream;   /* hipStream_t to enqueue on; NULL = library-owned stream */
+} lh_config;
+
+/* CLIMAParameters constants read by src/SoilModel/SoilHeatParameterizations.jl:12-13
+ * (Planet: rho_cloud_liq, rho_cloud_ice, cp_l, cp_i, T_0, LH_f0; Microphysics: K_therm). */
+typedef struct {
+    double rho_liq, rho_ice, cp_l, cp_i, T_0, LH_f0, K_therm;
+} lh_earth_params;
+
+/* SoilParams{FT}, src/SoilModel/parameters.jl:11-43 (physics fields) */
+typedef struct {
+    double nu, S_s, nu_ss_gravel, nu_ss_om, nu_ss_quartz, rho_c_ds, kappa_solid, rho_p,
+        kappa_sat_unfrozen, kappa_sat_frozen, a, b, kappa_dry_parameter;
+} lh_soil_params;
+
+/* vanGenuchten{FT}, SoilWaterParameterizations.jl:150-169 (m = 1 - 1/n is derived) */
+typedef struct {
+    double n, alpha, theta_r, Ksat;
+} lh_vg_params;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* SoilModel(FT; domain, energy_model, hydrology_model, ...) (models.jl:115-135).
+ * Starts with the reference defaults: loam vanGenuchten, default SoilParams,
+ * NoEffect factors, NoBC on every face/component; earth parameters must be set
+ * before lh_rhs when the model has an energy component. */
+int lh_create(lh_ctx** out, const lh_config* cfg);
+int lh_destroy(lh_ctx* ctx);
+/* message of the last failing call on ctx (ctx == NULL: last lh_create failure) */
+const char* lh_last_error(const lh_ctx* ctx);
+int lh_version(void);
+
+/* ---- parameters ----------------------------------------------------------- */
+
+int lh_set_earth_params(lh_ctx*, const lh_earth_params*);   /* SoilModel.earth_param_set */
+int lh_set_soil_params(lh_ctx*, const lh_soil_params*);     /* SoilModel.soil_param_set  */
+int lh_set_vg_params(lh_ctx*, const lh_vg_params*);         /* hydrology.hydraulic_model */
+/* per-column override of one parameter (host array of ncols doubles); NULL
+ * restores the scalar.  Build extension: the reference has one column. */
+int lh_set_percol_param(lh_ctx*, int32_t param_id, const double* host_values);
+/* SoilHydrologyModel.viscosity_factor / .impedance_factor (models.jl:28-33) */
+int lh_set_conductivity_factors(lh_ctx*, int32_t viscosity_kind, double gamma, double T_ref,
+                                int32_t impedance_kind, double Omega);
+/* SoilColumnBC(top = SoilComponentBC(energy=, hydrology=), bottom = ...)
+ * (boundary_conditions.jl:95-161).  value = VerticalFlux.flux, or
+ * Dirichlet.state_value(t) evaluated by the host shim for the current time;
+ * percol_values (ncols doubles) overrides value per column when not NULL. */
+int lh_set_bc(lh_ctx*, int32_t face, int32_t component, int32_t kind, double value,
+              const double* percol_values);
+/* 0 (default): bottom-face hydrology Dirichlet flux exactly as the reference
+ * writes it (boundary_conditions.jl:395-398); 1: physically consistent sign. */
+int lh_set_bottom_sign_consistent(lh_ctx*, int32_t flag);
+/* LH_MATH_* (default LH_MATH_FAST; the environment variable LH_MATH=libm
+ * selects LH_MATH_LIBM at lh_create) */
+int lh_set_math_mode(lh_ctx*, int32_t mode);
+
+/* ---- states ---------------------------------------------------------------- */
+
+/* Fields.FieldVector analogue.  var_mask selects the planes to allocate
+ * (LH_MASK(...)); 0 = the prognostic set of the model
+ * (initial_conditions.jl:85-89). */
+int lh_state_create(lh_ctx*, uint32_t var_mask, lh_state** out);
+int lh_state_destroy(lh_ctx*, lh_state*);
+/* host -> device / device -> host for one variable, FT elements */
+int lh_upload(lh_ctx*, lh_state*, int32_t var, const void* host, int64_t lev_stride,
+              int64_t col_stride);
+int lh_download(lh_ctx*, const lh_state*, int32_t var, void* host, int64_t lev_stride,
+                int64_t col_stride);
+int lh_state_fill(lh_ctx*, lh_state*, int32_t var, double value);
+int lh_state_copy(lh_ctx*, lh_state* dst, const lh_state* src);
+/* zero-copy access: device pointer of a plane and its element strides
+ * (column-fastest planes: col_stride == 1). */
+int lh_state_device_ptr(lh_ctx*, const lh_state*, int32_t var, void** dptr,
+                        int64_t* lev_stride, int64_t* col_stride);
+/* coordinates(cs) (right_hand_side.jl:7-8): cell-centre z, nlev doubles */
+int lh_coordinates(const lh_ctx*, double* zc_host);
+
+/* ---- the hot path ----------------------------------------------------------- */
+
+/* rhs!(dY, Y, Ya, t) (right_hand_side.jl:37-42).  Ya may be NULL when the model
+ * reads no auxiliary field (COUPLED; RICHARDS with NoEffect viscosity).  The
+ * prescribed-profile update of make_update_aux (:54-96) is the host shim's job:
+ * it uploads Ya when its closures depend on t. */
+int lh_rhs(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY);
+
+/* centre fields K, psi, kappa, T of the same pointwise stage
+ * (right_hand_side.jl:156-167, 291-314) into a 4-plane state (LH_DIAG_*) */
+int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out);
+
+/* solve(prob, SSPRK33(), dt = dt) (simulation.jl:58-87; coupled.jl:94): nsteps
+ * fixed-dt steps, Y advanced in place on the device.  bc_stage_values is NULL or
+ * [nsteps][3][2][2] doubles (step, stage, face, component): Dirichlet/flux
+ * values at the stage times t, t+dt, t+dt/2. */
+int lh_step_ssprk33(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double dt,
+                    int64_t nsteps, const double* bc_stage_values);
+
+/* Build-defined stable step (the reference uses a fixed user dt):
+ * min over owned cells of courant*dz^2/max(K dpsi/dvl, kappa/rho_c_s).
+ * _device leaves the FT result in device memory (for an RCCL min all-reduce
+ * across ranks without a host round trip); the host form synchronises. */
+int lh_stable_dt(lh_ctx*, const lh_state* Y, const lh_state* Ya, double courant,
+                 double* dt_host);
+int lh_stable_dt_device(lh_ctx*, const lh_state* Y, const lh_state* Ya, double courant,
+                        void* dt_device_ft);
+
+/* ---- status / timing -------------------------------------------------------- */
+
+/* bit 0: a non-finite tendency was produced since the last call (the reference
+ * would have raised DomainError from `^`); synchronises and clears. */
+int lh_get_status(lh_ctx*, uint32_t* flags);
+int lh_synchronize(lh_ctx*);
+/* HIP-event stopwatch on the context's stream */
+int lh_timer_start(lh_ctx*);
+int lh_timer_stop(lh_ctx*, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANDHYDRO_H */

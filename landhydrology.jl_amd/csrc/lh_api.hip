@@ -1,0 +1,725 @@
+// lh_api.hip -- the C ABI of liblandhydro_hip.so (include/landhydro.h).
+// Host logic only: parameter rounding, validation, state management, launches.
+// There is no CPU fallback: without a HIP device lh_create fails loudly.
+#include "../../include/landhydro.h"
+#include "lh_launch.hpp"
+#include "lh_fastmath.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace lh;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostParams {
+    lh_earth_params earth{};
+    bool earth_set = false;
+    lh_soil_params soil{};
+    lh_vg_params vg{};
+    int32_t viscosity_kind = LH_FACTOR_NONE, impedance_kind = LH_FACTOR_NONE;
+    double gamma = 2.64e-2, T_ref_visc = 288.0, Omega = 7.0; // SoilWaterParameterizations.jl:49-64
+    int32_t bc_kind[2][2] = {{0, 0}, {0, 0}};
+    double bc_value[2][2] = {{0, 0}, {0, 0}};
+    int32_t consistent_bottom_sign = 0;
+};
+
+} // namespace
+
+struct lh_state {
+    lh_ctx* ctx;
+    uint32_t mask;
+    void* plane[LH_NVARS];
+};
+
+struct lh_ctx {
+    lh_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t stride = 0; // plane row length (elements), multiple of 64
+    size_t esize = 8;
+    HostParams hp;
+    void* d_zc = nullptr;              // FT[nlev]
+    void* d_pc[LH_PC_COUNT] = {};      // FT[ncols] or null
+    void* d_bc_pc[2][2] = {};          // FT[ncols] or null
+    uint32_t* d_status = nullptr;
+    void* d_dt = nullptr;              // FT scratch for lh_stable_dt
+    lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int math = MATH_FAST;
+    std::vector<double> zc_host;
+    std::string err;
+    std::vector<lh_state*> states;
+};
+
+namespace {
+
+int fail(lh_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define LH_HIP(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LH_ENOMEM : LH_ENODEVICE,           \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                      \
+    } while (0)
+
+// Uniform mesh of domain.jl:58-69: faces are the correctly rounded
+// zmin + k L / n (Julia ranges step in twice precision), centres are face
+// midpoints in FT, bottom first (coupled.jl:198).
+template <typename FT>
+void make_grid(double zmin, double zmax, int n, std::vector<FT>& zc) {
+    zc.resize(n);
+    FT lo = FT(zmin), hi = FT(zmax), prev = lo;
+    for (int k = 1; k <= n; ++k) {
+        long double x = (long double)lo + ((long double)hi - (long double)lo) * k / n;
+        FT f = (k == n) ? hi : FT(x);
+        zc[k - 1] = (prev + f) / FT(2);
+        prev = f;
+    }
+}
+
+template <typename FT> FT host_pow(FT x, FT y);
+template <> double host_pow<double>(double x, double y) { return std::pow(x, y); }
+template <> float host_pow<float>(float x, float y) { return powf(x, y); }
+
+// Build the kernel argument, rounding to FT where the Julia constructors do.
+template <typename FT>
+DevParams<FT> make_params(const lh_ctx* c) {
+    const HostParams& h = c->hp;
+    DevParams<FT> P;
+    memset(&P, 0, sizeof P);
+    P.ncols = c->cfg.ncols;
+    P.stride = c->stride;
+    P.nlev = c->cfg.nlev;
+    P.model = c->cfg.model;
+    P.dz = (FT(c->cfg.zmax) - FT(c->cfg.zmin)) / FT(c->cfg.nlev);
+    P.inv_dz = FT(1) / P.dz;
+    P.half_dz = P.dz / FT(2);
+    P.zc = static_cast<const FT*>(c->d_zc);
+    P.vg_n = FT(h.vg.n);
+    P.vg_alpha = FT(h.vg.alpha);
+    P.vg_theta_r = FT(h.vg.theta_r);
+    P.vg_Ksat = FT(h.vg.Ksat);
+    P.nu = FT(h.soil.nu);
+    P.S_s = FT(h.soil.S_s);
+    P.rho_c_ds = FT(h.soil.rho_c_ds);
+    P.kappa_solid = FT(h.soil.kappa_solid);
+    P.rho_p = FT(h.soil.rho_p);
+    P.kappa_sat_unfrozen = FT(h.soil.kappa_sat_unfrozen);
+    P.kappa_sat_frozen = FT(h.soil.kappa_sat_frozen);
+    P.kappa_dry_parameter = FT(h.soil.kappa_dry_parameter);
+    P.nu_ss_om = FT(h.soil.nu_ss_om);
+    P.b = FT(h.soil.b);
+    const FT om = FT(h.soil.nu_ss_om), q = FT(h.soil.nu_ss_quartz), g = FT(h.soil.nu_ss_gravel),
+             a = FT(h.soil.a);
+    P.kersten_exp_unfrozen = (FT(1) + om - a * q - g) / FT(2); // SoilHeatParameterizations.jl:165
+    P.kersten_exp_frozen = FT(1) + om;                         // :171
+    P.one_minus_om = FT(1) - om;                               // :169
+    // FT(cp_l(param_set) * _rho_l): Float64 product of the constant and the
+    // already rounded density (SoilHeatParameterizations.jl:71-75)
+    P.rho_i = FT(h.earth.rho_ice);
+    const FT rho_l = FT(h.earth.rho_liq);
+    P.rhocp_i = FT(h.earth.cp_i * double(P.rho_i));
+    P.rhocp_l = FT(h.earth.cp_l * double(rho_l));
+    P.T_ref = FT(h.earth.T_0);
+    P.LH_f0 = FT(h.earth.LH_f0);
+    P.k_air = FT(h.earth.K_therm);
+    P.viscosity_kind = h.viscosity_kind;
+    P.impedance_kind = h.impedance_kind;
+    P.gamma = FT(h.gamma);
+    P.T_ref_visc = FT(h.T_ref_visc);
+    P.Omega = FT(h.Omega);
+    // uniform column constants, host libm
+    ColC<FT>& u = P.uc;
+    u.nu = P.nu;
+    u.S_s = P.S_s;
+    u.theta_r = P.vg_theta_r;
+    u.theta_lim = u.theta_r + Limits<FT>::eps();
+    u.n = P.vg_n;
+    u.inv_n = FT(1) / u.n;
+    u.m = FT(1) - FT(1) / u.n;
+    u.inv_m = FT(1) / u.m;
+    u.alpha_pnn = host_pow<FT>(P.vg_alpha, -u.n);
+    u.Ksat = P.vg_Ksat;
+    {
+        FT rho_b = (FT(1) - u.nu) * P.rho_p;
+        FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
+        FT den = P.rho_p - (FT(1) - P.kappa_dry_parameter) * rho_b;
+        u.k_dry = num / den;
+    }
+    for (int i = 0; i < LH_PC_COUNT; ++i) P.pc[i] = static_cast<const FT*>(c->d_pc[i]);
+    for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < 2; ++k) {
+            P.bc_kind[f][k] = h.bc_kind[f][k];
+            P.bc_value[f][k] = FT(h.bc_value[f][k]);
+            P.bc_pc[f][k] = static_cast<const FT*>(c->d_bc_pc[f][k]);
+        }
+    P.consistent_bottom_sign = h.consistent_bottom_sign;
+    P.status = c->d_status;
+    return P;
+}
+
+bool any_percol(const lh_ctx* c) {
+    for (int i = 0; i < LH_PC_COUNT; ++i)
+        if (c->d_pc[i]) return true;
+    return false;
+}
+
+bool model_water(int m) { return m != LH_MODEL_HEAT; }
+bool model_heat(int m) { return m != LH_MODEL_RICHARDS; }
+
+uint32_t prognostic_mask(int model) {
+    switch (model) {
+        case LH_MODEL_RICHARDS: return LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_THETA_I);
+        case LH_MODEL_HEAT: return LH_MASK(LH_VAR_RHOE_INT);
+        default: return LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_THETA_I) | LH_MASK(LH_VAR_RHOE_INT);
+    }
+}
+
+uint32_t aux_mask(const lh_ctx* c) {
+    if (c->cfg.model == LH_MODEL_HEAT) return LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_THETA_I);
+    if (c->cfg.model == LH_MODEL_RICHARDS && c->hp.viscosity_kind != LH_FACTOR_NONE)
+        return LH_MASK(LH_VAR_T);
+    return 0;
+}
+
+// The combinations for which the reference has a method; anything else raises
+// there (MethodError / SetValue(nothing)) and is LH_EMODEL here.
+int validate_model(lh_ctx* c) {
+    const HostParams& h = c->hp;
+    const int m = c->cfg.model;
+    for (int f = 0; f < 2; ++f) {
+        const int ke = h.bc_kind[f][LH_COMP_ENERGY], kh = h.bc_kind[f][LH_COMP_HYDROLOGY];
+        const char* fn = f == LH_FACE_TOP ? "top" : "bottom";
+        if (ke == LH_BC_FREE_DRAINAGE)
+            return fail(c, LH_EMODEL, "FreeDrainage is a hydrology boundary condition (%s energy)", fn);
+        if (model_heat(m)) {
+            if (ke == LH_BC_NONE)
+                return fail(c, LH_EMODEL, "SoilEnergyModel needs an energy boundary condition at the %s face (got NoBC)", fn);
+        } else if (ke == LH_BC_DIRICHLET) {
+            return fail(c, LH_EMODEL, "Dirichlet energy BC has no method for PrescribedTemperatureModel (%s)", fn);
+        }
+        if (model_water(m)) {
+            if (kh == LH_BC_NONE)
+                return fail(c, LH_EMODEL, "SoilHydrologyModel needs a hydrology boundary condition at the %s face (got NoBC)", fn);
+        } else if (kh == LH_BC_DIRICHLET || kh == LH_BC_FREE_DRAINAGE) {
+            return fail(c, LH_EMODEL, "hydrology BC of this kind has no method for PrescribedHydrologyModel (%s)", fn);
+        }
+    }
+    if (model_heat(m) && !h.earth_set)
+        return fail(c, LH_EINVAL, "earth parameters (lh_set_earth_params) are required by the energy model");
+    return LH_OK;
+}
+
+int check_state(lh_ctx* c, const lh_state* s, uint32_t need, const char* what) {
+    if (need == 0) return LH_OK;
+    if (!s) return fail(c, LH_ESTATE, "%s state is NULL but the model reads it", what);
+    if (s->ctx != c) return fail(c, LH_EINVAL, "%s state belongs to another context", what);
+    if ((s->mask & need) != need)
+        return fail(c, LH_ESTATE, "%s state lacks a required variable (has mask 0x%x, needs 0x%x)", what, s->mask, need);
+    return LH_OK;
+}
+
+template <typename FT>
+Planes<FT> planes_of(const lh_state* s) {
+    Planes<FT> p;
+    for (int i = 0; i < LH_NVARS; ++i) p.v[i] = s ? static_cast<FT*>(s->plane[i]) : nullptr;
+    return p;
+}
+
+template <typename FT>
+int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
+           double dt, int mode, const double* bc_override) {
+    DevParams<FT> P = make_params<FT>(c);
+    if (bc_override)
+        for (int f = 0; f < 2; ++f)
+            for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);
+    const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    launch_rhs<FT>(P, planes_of<FT>(in), planes_of<FT>(aux), planes_of<FT>(base), planes_of<FT>(out),
+                   FT(dt), mode, factors, any_percol(c), c->math, c->stream);
+    LH_HIP(c, hipGetLastError());
+    return LH_OK;
+}
+
+int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
+    lh_state* s = new (std::nothrow) lh_state();
+    if (!s) return fail(c, LH_ENOMEM, "out of host memory");
+    s->ctx = c;
+    s->mask = mask;
+    const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+    for (int i = 0; i < LH_NVARS; ++i) {
+        s->plane[i] = nullptr;
+        if (mask & (1u << i)) {
+            hipError_t e = hipMalloc(&s->plane[i], bytes);
+            if (e != hipSuccess) {
+                for (int j = 0; j < i; ++j)
+                    if (s->plane[j]) (void)hipFree(s->plane[j]);
+                delete s;
+                return fail(c, LH_ENOMEM, "hipMalloc of a %zu-byte plane failed: %s", bytes, hipGetErrorString(e));
+            }
+            e = hipMemsetAsync(s->plane[i], 0, bytes, c->stream);
+            if (e != hipSuccess) return fail(c, LH_ENODEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+    }
+    c->states.push_back(s);
+    *out = s;
+    return LH_OK;
+}
+
+void state_free(lh_ctx* c, lh_state* s) {
+    for (int i = 0; i < LH_NVARS; ++i)
+        if (s->plane[i]) (void)hipFree(s->plane[i]);
+    for (size_t i = 0; i < c->states.size(); ++i)
+        if (c->states[i] == s) {
+            c->states.erase(c->states.begin() + i);
+            break;
+        }
+    delete s;
+}
+
+int upload_percol(lh_ctx* c, void** slot, const double* host) {
+    if (*slot) {
+        LH_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(*slot);
+        *slot = nullptr;
+    }
+    if (!host) return LH_OK;
+    const int64_t n = c->cfg.ncols;
+    double* tmp = nullptr;
+    LH_HIP(c, hipMalloc(&tmp, size_t(n) * sizeof(double)));
+    hipError_t e = hipMalloc(slot, size_t(n) * c->esize);
+    if (e != hipSuccess) {
+        (void)hipFree(tmp);
+        return fail(c, LH_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    LH_HIP(c, hipMemcpyAsync(tmp, host, size_t(n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->cfg.dtype == LH_F64) launch_convert<double>(static_cast<double*>(*slot), tmp, n, c->stream);
+    else launch_convert<float>(static_cast<float*>(*slot), tmp, n, c->stream);
+    LH_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    return LH_OK;
+}
+
+} // namespace
+
+// ============================================================== C ABI
+
+extern "C" {
+
+int lh_version(void) { return LH_VERSION_MAJOR * 100 + LH_VERSION_MINOR; }
+
+const char* lh_last_error(const lh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lh_create(lh_ctx** out, const lh_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, LH_EINVAL, "lh_create: NULL argument");
+    *out = nullptr;
+    if (cfg->ncols < 1 || cfg->nlev < 1) return fail(nullptr, LH_EINVAL, "lh_create: ncols and nlev must be >= 1");
+    if (!(cfg->zmin < cfg->zmax)) return fail(nullptr, LH_EINVAL, "lh_create: zlim[1] < zlim[2] required (domain.jl:30)");
+    if (cfg->dtype != LH_F32 && cfg->dtype != LH_F64) return fail(nullptr, LH_EINVAL, "lh_create: dtype must be LH_F32 or LH_F64");
+    if (cfg->model < LH_MODEL_RICHARDS || cfg->model > LH_MODEL_COUPLED) return fail(nullptr, LH_EINVAL, "lh_create: unknown model");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, LH_ENODEVICE, "lh_create: no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    int dev = cfg->device;
+    if (dev < 0) {
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess) return fail(nullptr, LH_ENODEVICE, "hipGetDevice failed: %s", hipGetErrorString(e));
+    }
+    if (dev >= ndev) return fail(nullptr, LH_EINVAL, "lh_create: device %d out of range (%d devices)", dev, ndev);
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) return fail(nullptr, LH_ENODEVICE, "hipSetDevice(%d) failed: %s", dev, hipGetErrorString(e));
+
+    lh_ctx* c = new (std::nothrow) lh_ctx();
+    if (!c) return fail(nullptr, LH_ENOMEM, "out of host memory");
+    c->cfg = *cfg;
+    c->device = dev;
+    c->esize = cfg->dtype == LH_F64 ? 8 : 4;
+    c->stride = (cfg->ncols + 63) / 64 * 64;
+    // reference defaults: loam vanGenuchten, default SoilParams
+    c->hp.vg = lh_vg_params{1.56, 3.6, 0.0, 2.9e-7};
+    c->hp.soil = lh_soil_params{0.43, 1e-3, 0.0, 0.0, 0.41, 2700.0, 3.97, 2700.0, 1.72, 3.13, 0.24, 18.1, 0.053};
+    if (const char* m = getenv("LH_MATH"))
+        if (!strcmp(m, "libm")) c->math = MATH_LIBM;
+
+#define CREATE_HIP(call)                                                                           \
+    do {                                                                                           \
+        hipError_t e2_ = (call);                                                                   \
+        if (e2_ != hipSuccess) {                                                                   \
+            int rc_ = fail(nullptr, e2_ == hipErrorOutOfMemory ? LH_ENOMEM : LH_ENODEVICE,         \
+                           "lh_create: %s failed: %s", #call, hipGetErrorString(e2_));             \
+            lh_destroy(c);                                                                         \
+            return rc_;                                                                            \
+        }                                                                                          \
+    } while (0)
+
+    if (cfg->stream) {
+        c->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+        CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    CREATE_HIP(hipEventCreate(&c->ev0));
+    CREATE_HIP(hipEventCreate(&c->ev1));
+    CREATE_HIP(hipMalloc(&c->d_zc, size_t(cfg->nlev) * c->esize));
+    CREATE_HIP(hipMalloc(&c->d_status, sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
+    CREATE_HIP(hipMalloc(&c->d_dt, 8));
+    c->zc_host.resize(cfg->nlev);
+    if (cfg->dtype == LH_F64) {
+        std::vector<double> z;
+        make_grid<double>(cfg->zmin, cfg->zmax, cfg->nlev, z);
+        for (int i = 0; i < cfg->nlev; ++i) c->zc_host[i] = z[i];
+        CREATE_HIP(hipMemcpy(c->d_zc, z.data(), z.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> z;
+        make_grid<float>(cfg->zmin, cfg->zmax, cfg->nlev, z);
+        for (int i = 0; i < cfg->nlev; ++i) c->zc_host[i] = z[i];
+        CREATE_HIP(hipMemcpy(c->d_zc, z.data(), z.size() * 4, hipMemcpyHostToDevice));
+    }
+#undef CREATE_HIP
+    *out = c;
+    return LH_OK;
+}
+
+int lh_destroy(lh_ctx* c) {
+    if (!c) return LH_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    while (!c->states.empty()) state_free(c, c->states.back());
+    for (int i = 0; i < LH_PC_COUNT; ++i)
+        if (c->d_pc[i]) (void)hipFree(c->d_pc[i]);
+    for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < 2; ++k)
+            if (c->d_bc_pc[f][k]) (void)hipFree(c->d_bc_pc[f][k]);
+    if (c->d_zc) (void)hipFree(c->d_zc);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_dt) (void)hipFree(c->d_dt);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LH_OK;
+}
+
+int lh_set_earth_params(lh_ctx* c, const lh_earth_params* p) {
+    if (!c || !p) return fail(c, LH_EINVAL, "lh_set_earth_params: NULL argument");
+    c->hp.earth = *p;
+    c->hp.earth_set = true;
+    return LH_OK;
+}
+
+int lh_set_soil_params(lh_ctx* c, const lh_soil_params* p) {
+    if (!c || !p) return fail(c, LH_EINVAL, "lh_set_soil_params: NULL argument");
+    c->hp.soil = *p;
+    return LH_OK;
+}
+
+int lh_set_vg_params(lh_ctx* c, const lh_vg_params* p) {
+    if (!c || !p) return fail(c, LH_EINVAL, "lh_set_vg_params: NULL argument");
+    c->hp.vg = *p;
+    return LH_OK;
+}
+
+int lh_set_percol_param(lh_ctx* c, int32_t id, const double* host) {
+    if (!c) return LH_EINVAL;
+    if (id < 0 || id >= LH_PC_COUNT) return fail(c, LH_EINVAL, "lh_set_percol_param: unknown parameter id %d", id);
+    (void)hipSetDevice(c->device);
+    return upload_percol(c, &c->d_pc[id], host);
+}
+
+int lh_set_conductivity_factors(lh_ctx* c, int32_t vk, double gamma, double T_ref, int32_t ik, double Omega) {
+    if (!c) return LH_EINVAL;
+    if ((vk != LH_FACTOR_NONE && vk != LH_FACTOR_ON) || (ik != LH_FACTOR_NONE && ik != LH_FACTOR_ON))
+        return fail(c, LH_EINVAL, "lh_set_conductivity_factors: kind must be LH_FACTOR_NONE or LH_FACTOR_ON");
+    c->hp.viscosity_kind = vk;
+    c->hp.impedance_kind = ik;
+    c->hp.gamma = gamma;
+    c->hp.T_ref_visc = T_ref;
+    c->hp.Omega = Omega;
+    return LH_OK;
+}
+
+int lh_set_bc(lh_ctx* c, int32_t face, int32_t comp, int32_t kind, double value, const double* percol) {
+    if (!c) return LH_EINVAL;
+    if (face != LH_FACE_BOTTOM && face != LH_FACE_TOP)
+        return fail(c, LH_EINVAL, "Expected :top or :bottom"); // boundary_conditions.jl:188
+    if (comp != LH_COMP_ENERGY && comp != LH_COMP_HYDROLOGY) return fail(c, LH_EINVAL, "lh_set_bc: unknown component %d", comp);
+    if (kind < LH_BC_NONE || kind > LH_BC_FREE_DRAINAGE) return fail(c, LH_EINVAL, "lh_set_bc: unknown kind %d", kind);
+    c->hp.bc_kind[face][comp] = kind;
+    c->hp.bc_value[face][comp] = value;
+    (void)hipSetDevice(c->device);
+    return upload_percol(c, &c->d_bc_pc[face][comp], percol);
+}
+
+int lh_set_bottom_sign_consistent(lh_ctx* c, int32_t flag) {
+    if (!c) return LH_EINVAL;
+    c->hp.consistent_bottom_sign = flag ? 1 : 0;
+    return LH_OK;
+}
+
+int lh_set_math_mode(lh_ctx* c, int32_t mode) {
+    if (!c) return LH_EINVAL;
+    if (mode != LH_MATH_FAST && mode != LH_MATH_LIBM) return fail(c, LH_EINVAL, "lh_set_math_mode: unknown mode %d", mode);
+    c->math = mode == LH_MATH_LIBM ? MATH_LIBM : MATH_FAST;
+    return LH_OK;
+}
+
+int lh_state_create(lh_ctx* c, uint32_t mask, lh_state** out) {
+    if (!c || !out) return fail(c, LH_EINVAL, "lh_state_create: NULL argument");
+    if (mask == 0) mask = prognostic_mask(c->cfg.model);
+    if (mask >= (1u << LH_NVARS)) return fail(c, LH_EINVAL, "lh_state_create: bad variable mask 0x%x", mask);
+    (void)hipSetDevice(c->device);
+    return state_alloc(c, mask, out);
+}
+
+int lh_state_destroy(lh_ctx* c, lh_state* s) {
+    if (!c || !s) return LH_OK;
+    if (s->ctx != c) return fail(c, LH_EINVAL, "lh_state_destroy: state belongs to another context");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch_u1 == s) c->scratch_u1 = nullptr;
+    state_free(c, s);
+    return LH_OK;
+}
+
+static int transfer(lh_ctx* c, lh_state* s, int32_t var, void* host, int64_t ls, int64_t cs, bool upload) {
+    if (!c || !s || !host) return fail(c, LH_EINVAL, "lh_upload/lh_download: NULL argument");
+    if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    if (ls < 1 || cs < 1) return fail(c, LH_EINVAL, "strides must be >= 1");
+    (void)hipSetDevice(c->device);
+    const int64_t ncols = c->cfg.ncols;
+    const int nlev = c->cfg.nlev;
+    const size_t es = c->esize;
+    char* plane = static_cast<char*>(s->plane[var]);
+    if (cs == 1 && ls >= ncols) { // already column-fastest: one 2-D copy
+        if (upload)
+            LH_HIP(c, hipMemcpy2DAsync(plane, size_t(c->stride) * es, host, size_t(ls) * es, size_t(ncols) * es, nlev, hipMemcpyHostToDevice, c->stream));
+        else
+            LH_HIP(c, hipMemcpy2DAsync(host, size_t(ls) * es, plane, size_t(c->stride) * es, size_t(ncols) * es, nlev, hipMemcpyDeviceToHost, c->stream));
+        LH_HIP(c, hipStreamSynchronize(c->stream));
+        return LH_OK;
+    }
+    const int64_t span = (ncols - 1) * cs + int64_t(nlev - 1) * ls + 1;
+    void* tmp = nullptr;
+    LH_HIP(c, hipMalloc(&tmp, size_t(span) * es));
+    hipError_t e = hipSuccess;
+    if (upload) e = hipMemcpyAsync(tmp, host, size_t(span) * es, hipMemcpyHostToDevice, c->stream);
+    else if (span != ncols * int64_t(nlev)) // gaps in the user layout keep their contents
+        e = hipMemcpyAsync(tmp, host, size_t(span) * es, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        if (c->cfg.dtype == LH_F64)
+            launch_strided_copy<double>(reinterpret_cast<double*>(plane), c->stride, static_cast<double*>(tmp), ls, cs, ncols, nlev, upload, c->stream);
+        else
+            launch_strided_copy<float>(reinterpret_cast<float*>(plane), c->stride, static_cast<float*>(tmp), ls, cs, ncols, nlev, upload, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !upload) e = hipMemcpyAsync(host, tmp, size_t(span) * es, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, LH_ENODEVICE, "transfer failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(c, LH_ENODEVICE, "transfer failed: %s", hipGetErrorString(e2));
+    return LH_OK;
+}
+
+int lh_upload(lh_ctx* c, lh_state* s, int32_t var, const void* host, int64_t ls, int64_t cs) {
+    return transfer(c, s, var, const_cast<void*>(host), ls, cs, true);
+}
+
+int lh_download(lh_ctx* c, const lh_state* s, int32_t var, void* host, int64_t ls, int64_t cs) {
+    return transfer(c, const_cast<lh_state*>(s), var, host, ls, cs, false);
+}
+
+int lh_state_fill(lh_ctx* c, lh_state* s, int32_t var, double value) {
+    if (!c || !s) return fail(c, LH_EINVAL, "lh_state_fill: NULL argument");
+    if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    (void)hipSetDevice(c->device);
+    const int64_t n = int64_t(c->cfg.nlev) * c->stride;
+    if (c->cfg.dtype == LH_F64) launch_fill<double>(static_cast<double*>(s->plane[var]), n, value, c->stream);
+    else launch_fill<float>(static_cast<float*>(s->plane[var]), n, float(value), c->stream);
+    LH_HIP(c, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_state_copy(lh_ctx* c, lh_state* dst, const lh_state* src) {
+    if (!c || !dst || !src) return fail(c, LH_EINVAL, "lh_state_copy: NULL argument");
+    if (dst->ctx != c || src->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if ((dst->mask & src->mask) != src->mask) return fail(c, LH_ESTATE, "lh_state_copy: destination lacks planes of the source");
+    (void)hipSetDevice(c->device);
+    const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+    for (int i = 0; i < LH_NVARS; ++i)
+        if (src->mask & (1u << i))
+            LH_HIP(c, hipMemcpyAsync(dst->plane[i], src->plane[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+    return LH_OK;
+}
+
+int lh_state_device_ptr(lh_ctx* c, const lh_state* s, int32_t var, void** dptr, int64_t* ls, int64_t* cs) {
+    if (!c || !s || !dptr) return fail(c, LH_EINVAL, "lh_state_device_ptr: NULL argument");
+    if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    *dptr = s->plane[var];
+    if (ls) *ls = c->stride;
+    if (cs) *cs = 1;
+    return LH_OK;
+}
+
+int lh_coordinates(const lh_ctx* c, double* zc) {
+    if (!c || !zc) return LH_EINVAL;
+    memcpy(zc, c->zc_host.data(), c->zc_host.size() * sizeof(double));
+    return LH_OK;
+}
+
+int lh_rhs(lh_ctx* c, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY) {
+    (void)t; // boundary/aux closures of t are evaluated by the host shim
+    if (!c) return LH_EINVAL;
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, dY, pm, "dY"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    return c->cfg.dtype == LH_F64 ? do_rhs<double>(c, Y, Ya, nullptr, dY, 0.0, 0, nullptr)
+                                  : do_rhs<float>(c, Y, Ya, nullptr, dY, 0.0, 0, nullptr);
+}
+
+int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* out) {
+    if (!c) return LH_EINVAL;
+    int rc;
+    if (model_heat(c->cfg.model) && !c->hp.earth_set)
+        return fail(c, LH_EINVAL, "earth parameters (lh_set_earth_params) are required by the energy model");
+    if ((rc = check_state(c, Y, prognostic_mask(c->cfg.model), "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    if ((rc = check_state(c, out, 0xFu, "diagnostic"))) return rc;
+    (void)hipSetDevice(c->device);
+    if (c->cfg.dtype == LH_F64) {
+        DevParams<double> P = make_params<double>(c);
+        launch_diag<double>(P, planes_of<double>(Y), planes_of<double>(Ya), planes_of<double>(out), any_percol(c), c->math, c->stream);
+    } else {
+        DevParams<float> P = make_params<float>(c);
+        launch_diag<float>(P, planes_of<float>(Y), planes_of<float>(Ya), planes_of<float>(out), any_percol(c), c->math, c->stream);
+    }
+    LH_HIP(c, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double dt, int64_t nsteps,
+                    const double* bcv) {
+    (void)t;
+    if (!c) return LH_EINVAL;
+    if (nsteps < 0 || !(dt > 0)) return fail(c, LH_EINVAL, "lh_step_ssprk33: need nsteps >= 0 and dt > 0");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    if (!c->scratch_u1 && (rc = state_alloc(c, pm, &c->scratch_u1))) return rc;
+    lh_state* U1 = c->scratch_u1;
+    for (int64_t s = 0; s < nsteps; ++s) {
+        for (int stage = 0; stage < 3; ++stage) {
+            const double* ov = bcv ? bcv + (s * 3 + stage) * 4 : nullptr;
+            // stage 1: U1 = Y + dt f(Y); 2: U1 = (3Y + U1 + dt f(U1))/4; 3: Y = (Y + 2U1 + 2dt f(U1))/3
+            const lh_state* in = stage == 0 ? Y : U1;
+            lh_state* out = stage == 2 ? Y : U1;
+            rc = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, dt, stage + 1, ov)
+                                        : do_rhs<float>(c, in, Ya, Y, out, dt, stage + 1, ov);
+            if (rc) return rc;
+        }
+    }
+    return LH_OK;
+}
+
+int lh_stable_dt_device(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double courant, void* d_out) {
+    if (!c || !d_out) return fail(c, LH_EINVAL, "lh_stable_dt_device: NULL argument");
+    int rc;
+    if (model_heat(c->cfg.model) && !c->hp.earth_set)
+        return fail(c, LH_EINVAL, "earth parameters (lh_set_earth_params) are required by the energy model");
+    if ((rc = check_state(c, Y, prognostic_mask(c->cfg.model), "Y"))) return rc;
+    uint32_t am = c->cfg.model == LH_MODEL_HEAT ? aux_mask(c) : 0;
+    if ((rc = check_state(c, Ya, am, "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    if (c->cfg.dtype == LH_F64) {
+        DevParams<double> P = make_params<double>(c);
+        launch_stable_dt<double>(P, planes_of<double>(Y), planes_of<double>(Ya), courant, d_out, any_percol(c), c->stream);
+    } else {
+        DevParams<float> P = make_params<float>(c);
+        launch_stable_dt<float>(P, planes_of<float>(Y), planes_of<float>(Ya), float(courant), d_out, any_percol(c), c->stream);
+    }
+    LH_HIP(c, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_stable_dt(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double courant, double* dt_host) {
+    if (!c || !dt_host) return fail(c, LH_EINVAL, "lh_stable_dt: NULL argument");
+    int rc = lh_stable_dt_device(c, Y, Ya, courant, c->d_dt);
+    if (rc) return rc;
+    if (c->cfg.dtype == LH_F64) {
+        double v;
+        LH_HIP(c, hipMemcpyAsync(&v, c->d_dt, 8, hipMemcpyDeviceToHost, c->stream));
+        LH_HIP(c, hipStreamSynchronize(c->stream));
+        *dt_host = v;
+    } else {
+        float v;
+        LH_HIP(c, hipMemcpyAsync(&v, c->d_dt, 4, hipMemcpyDeviceToHost, c->stream));
+        LH_HIP(c, hipStreamSynchronize(c->stream));
+        *dt_host = v;
+    }
+    return LH_OK;
+}
+
+int lh_get_status(lh_ctx* c, uint32_t* flags) {
+    if (!c || !flags) return LH_EINVAL;
+    (void)hipSetDevice(c->device);
+    LH_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LH_HIP(c, hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
+    LH_HIP(c, hipStreamSynchronize(c->stream));
+    return LH_OK;
+}
+
+int lh_synchronize(lh_ctx* c) {
+    if (!c) return LH_EINVAL;
+    (void)hipSetDevice(c->device);
+    LH_HIP(c, hipStreamSynchronize(c->stream));
+    return LH_OK;
+}
+
+int lh_timer_start(lh_ctx* c) {
+    if (!c) return LH_EINVAL;
+    (void)hipSetDevice(c->device);
+    LH_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return LH_OK;
+}
+
+int lh_timer_stop(lh_ctx* c, float* ms) {
+    if (!c || !ms) return LH_EINVAL;
+    (void)hipSetDevice(c->device);
+    LH_HIP(c, hipEventRecord(c->ev1, c->stream));
+    LH_HIP(c, hipEventSynchronize(c->ev1));
+    LH_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return LH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,188 @@
+// lh_closures.hpp -- pointwise soil closures on the device (gfx950).
+//
+// The formulas are those of src/SoilModel/SoilWaterParameterizations.jl and
+// src/SoilModel/SoilHeatParameterizations.jl in the reference, evaluated per
+// lane (lane = soil column).  `M` is the math policy: MathLibm (ocml pow/exp,
+// <= 1 ulp) or MathFast (lh_fastmath.hpp, table-free log2/exp2 kernels tuned
+// for gfx950).
+#pragma once
+#include "lh_device.hpp"
+#include "lh_fastmath.hpp"
+
+namespace lh {
+
+template <typename FT, typename M>
+__device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t col, bool percol) {
+    if (!percol) return P.uc;
+    ColC<FT> c;
+    FT n = P.vg_n, alpha = P.vg_alpha;
+    c.theta_r = P.vg_theta_r;
+    c.Ksat = P.vg_Ksat;
+    c.nu = P.nu;
+    c.S_s = P.S_s;
+    {
+        if (P.pc[PC_VG_N]) n = P.pc[PC_VG_N][col];
+        if (P.pc[PC_VG_ALPHA]) alpha = P.pc[PC_VG_ALPHA][col];
+        if (P.pc[PC_VG_THETA_R]) c.theta_r = P.pc[PC_VG_THETA_R][col];
+        if (P.pc[PC_VG_KSAT]) c.Ksat = P.pc[PC_VG_KSAT][col];
+        if (P.pc[PC_NU]) c.nu = P.pc[PC_NU][col];
+        if (P.pc[PC_S_S]) c.S_s = P.pc[PC_S_S][col];
+    }
+    c.n = n;
+    c.inv_n = FT(1) / n;
+    c.m = FT(1) - FT(1) / n; // vanGenuchten constructor, SoilWaterParameterizations.jl:167
+    c.inv_m = FT(1) / c.m;
+    c.alpha_pnn = MathLibm<FT>::pow(alpha, -n); // once per column
+    c.theta_lim = c.theta_r + Limits<FT>::eps();
+    // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
+    FT rho_b = (FT(1) - c.nu) * P.rho_p;
+    FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
+    FT den = P.rho_p - (FT(1) - P.kappa_dry_parameter) * rho_b;
+    c.k_dry = num / den;
+    return c;
+}
+
+// volumetric_liquid_fraction, SoilWaterParameterizations.jl:180-187
+template <typename FT>
+__device__ __forceinline__ FT liquid_fraction(FT vl, FT nu_eff) {
+    return (vl < nu_eff) ? vl : nu_eff;
+}
+
+// K and psi of one cell: right_hand_side.jl:156-167 / :308-313 with
+// effective_saturation (:212-216), hydraulic_conductivity (:268-281),
+// pressure_head (:228-241), matric_potential (:195-199), the conductivity
+// factors (:76-126).  K uses the true porosity nu, psi uses nu_eff = nu - ti.
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
+__device__ __forceinline__ void water_closures(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
+                                               FT ti, FT T, FT& K, FT& psi) {
+    const FT nu_eff = c.nu - ti;
+    const FT vls = (vl > c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps)
+    const FT num = vls - c.theta_r;
+    const FT S = num / (c.nu - c.theta_r);
+    // when ti == 0, nu_eff == nu bitwise and the two saturations coincide
+    const FT Se = (nu_eff == c.nu) ? S : num / (nu_eff - c.theta_r);
+
+    FT Kr;
+    FT t_S = FT(0); // S^(1/m), reused by psi when Se == S
+    if (S < FT(1)) {
+        t_S = M::pow(S, c.inv_m);
+        FT inner = FT(1) - M::pow(FT(1) - t_S, c.m);
+        Kr = M::sqrt(S) * (inner * inner); // (.)^FT(2)
+    } else {
+        Kr = FT(1);
+    }
+    K = Kr * c.Ksat;
+    if (FACTORS) {
+        FT visc = FT(1), imp = FT(1);
+        if (P.viscosity_kind) visc = M::exp(P.gamma * (T - P.T_ref_visc));
+        if (P.impedance_kind) {
+            FT tl = liquid_fraction(vl, nu_eff);
+            FT f_i = ti / (tl + ti);
+            // FT(10.0^(-Omega*f_i)): Float64 power, rounded to FT (:89-93)
+            imp = FT(MathLibm<double>::pow(10.0, double(-P.Omega * f_i)));
+        }
+        K = K * visc * imp;
+    }
+    if (WANT_PSI) {
+        if (Se <= FT(1)) {
+            // S^(-1/m): share the power with K when the saturations coincide
+            FT r = (Se == S && S < FT(1)) ? M::rcp(t_S) : M::pow(Se, -c.inv_m);
+            psi = -M::pow((r - FT(1)) * c.alpha_pnn, c.inv_n);
+        } else {
+            psi = (vl - nu_eff) / c.S_s;
+        }
+    }
+}
+
+// T, kappa (and rho_c_s) of one cell: right_hand_side.jl:291-305 with
+// volumetric_heat_capacity (:65-79), temperature_from_rhoe_int (:42-53),
+// relative_saturation (:139-142), kersten_number (:152-174),
+// saturated_thermal_conductivity (:114-128), thermal_conductivity (:185-188).
+template <typename FT, typename M>
+__device__ __forceinline__ FT kappa_closure(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
+                                            FT ti) {
+    const FT nu_eff = c.nu - ti;
+    const FT tl = liquid_fraction(vl, nu_eff);
+    const FT tw = tl + ti;
+    const FT S_r = tw / c.nu;
+    FT K_e;
+    if (ti < Limits<FT>::eps()) {
+        FT e = M::exp(-P.b * S_r);
+        FT a = M::pow_neg3(FT(1) + e);          // (1 + exp(-b S_r))^(-3)
+        FT h = (FT(1) - S_r) / FT(2);
+        FT d = a - h * h * h;                   // ((1 - S_r)/2)^3
+        K_e = M::pow(S_r, P.kersten_exp_unfrozen) * M::pow(d, P.one_minus_om);
+    } else {
+        K_e = M::pow(S_r, P.kersten_exp_frozen);
+    }
+    FT k_sat;
+    if (tw < Limits<FT>::eps()) {
+        k_sat = FT(0);
+    } else if (ti == FT(0)) {
+        // kappa_unf^(tl/tw) * kappa_fr^0 with tl/tw == 1 exactly
+        k_sat = P.kappa_sat_unfrozen;
+    } else {
+        k_sat = M::pow(P.kappa_sat_unfrozen, tl / tw) * M::pow(P.kappa_sat_frozen, ti / tw);
+    }
+    return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
+}
+
+template <typename FT>
+__device__ __forceinline__ FT temperature_closure(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
+                                                  FT ti, FT rhoe, FT& rho_c_s) {
+    const FT nu_eff = c.nu - ti;
+    const FT tl = liquid_fraction(vl, nu_eff);
+    rho_c_s = P.rho_c_ds + tl * P.rhocp_l + ti * P.rhocp_i;
+    return P.T_ref + (rhoe + ti * P.rho_i * P.LH_f0) / rho_c_s;
+}
+
+// boundary_fluxes for one face of one column: boundary_conditions.jl:470-489
+// with :218-288 (centre/face pairs, Dirichlet overwrite) and the vertical_flux
+// methods :295-444.  (vl_c, ti_c, T_c, K_c, psi_c) are the centre values next
+// to the face; K_c/psi_c are the values the interior stage already computed
+// (the reference recomputes them on a 2-element array: same numbers).
+template <typename FT, typename M, int MODEL, bool FACTORS>
+__device__ __forceinline__ void boundary_fluxes(const DevParams<FT>& P, const ColC<FT>& c,
+                                                int face, int64_t col, FT vl_c, FT ti_c, FT T_c,
+                                                FT K_c, FT psi_c, FT& f_e, FT& f_w) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    const int ke = P.bc_kind[face][COMP_ENERGY];
+    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
+    FT ve = P.bc_value[face][COMP_ENERGY], vh = P.bc_value[face][COMP_HYDROLOGY];
+    if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
+    if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
+
+    FT vl_f = vl_c, T_f = T_c; // face := centre (:218-228)
+    if (HEAT && ke == BC_DIRICHLET) T_f = ve;
+    if (WATER && kh == BC_DIRICHLET) vl_f = vh;
+    const FT dzb = P.half_dz;
+    const FT sgn = (face == FACE_BOTTOM) ? FT(-1) : FT(1);
+
+    f_e = FT(0);
+    f_w = FT(0);
+    if (HEAT) {
+        if (ke == BC_FLUX) {
+            f_e = ve;
+        } else if (ke == BC_DIRICHLET) { // :416-444
+            FT kap_f = kappa_closure<FT, M>(P, c, vl_f, ti_c);
+            f_e = sgn * (-kap_f * (T_f - T_c) / dzb);
+        }
+    }
+    if (WATER) {
+        if (kh == BC_FLUX) {
+            f_w = vh;
+        } else if (kh == BC_FREE_DRAINAGE) { // :328-356
+            f_w = -K_c;
+        } else if (kh == BC_DIRICHLET) { // :371-401
+            FT K_f, psi_f;
+            water_closures<FT, M, FACTORS>(P, c, vl_f, ti_c, T_f, K_f, psi_f);
+            if (face == FACE_BOTTOM && P.consistent_bottom_sign)
+                f_w = K_f * (psi_f - psi_c - dzb) / dzb;
+            else
+                f_w = sgn * (-K_f * (psi_f - psi_c + dzb) / dzb);
+        }
+    }
+}
+
+} // namespace lh

@@ -1,0 +1,73 @@
+// lh_device.hpp -- kernel-argument structs shared by the host API (lh_api.hip)
+// and the gfx950 kernels (lh_kernels.hip).  Product code: nothing here touches
+// the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lh {
+
+enum { MODEL_RICHARDS = 0, MODEL_HEAT = 1, MODEL_COUPLED = 2 };
+enum { BC_NONE = 0, BC_FLUX = 1, BC_DIRICHLET = 2, BC_FREE_DRAINAGE = 3 };
+enum { FACE_BOTTOM = 0, FACE_TOP = 1 };
+enum { COMP_ENERGY = 0, COMP_HYDROLOGY = 1 };
+enum { PC_VG_N = 0, PC_VG_ALPHA, PC_VG_THETA_R, PC_VG_KSAT, PC_NU, PC_S_S, PC_COUNT };
+
+// per-column constants derived from vanGenuchten / SoilParams; one set per lane
+// (uniform ensembles: computed once on the host, see DevParams::uc)
+template <typename FT>
+struct ColC {
+    FT nu, S_s, theta_r, theta_lim; // theta_lim = theta_r + eps(FT)
+    FT n, inv_n, m, inv_m;          // m = 1 - 1/n (SoilWaterParameterizations.jl:167)
+    FT alpha_pnn;                   // alpha^(-n)
+    FT Ksat;
+    FT k_dry;                       // SoilHeatParameterizations.jl:280-294
+};
+
+// Everything a launch needs, already rounded to the working type FT the way the
+// Julia constructors round (FT(x)); passed by value as the kernel argument.
+template <typename FT>
+struct DevParams {
+    int64_t ncols;   // columns owned by this context
+    int64_t stride;  // elements between consecutive levels of a plane (>= ncols, multiple of 64)
+    int32_t nlev;
+    int32_t model;
+    FT dz;        // (zmax - zmin) / nlev            (domain.jl:64)
+    FT inv_dz;    // 1 / dz
+    FT half_dz;   // boundary centre-to-face distance (boundary_conditions.jl:196-208)
+    const FT* zc; // device array [nlev], coordinates(cs)
+
+    // vanGenuchten{FT} (SoilWaterParameterizations.jl:150-169)
+    FT vg_n, vg_alpha, vg_theta_r, vg_Ksat;
+    // SoilParams{FT} (parameters.jl:11-43)
+    FT nu, S_s, rho_c_ds, kappa_solid, rho_p, kappa_sat_unfrozen, kappa_sat_frozen,
+        kappa_dry_parameter, nu_ss_om, b;
+    FT kersten_exp_unfrozen; // (1 + nu_om - a*nu_q - nu_g)/2  (SoilHeatParameterizations.jl:165)
+    FT kersten_exp_frozen;   // 1 + nu_om                      (:171)
+    FT one_minus_om;         // 1 - nu_om                      (:169)
+    // CLIMAParameters constants as SoilHeatParameterizations.jl forms them
+    FT rho_i, rhocp_l, rhocp_i, T_ref, LH_f0, k_air;
+    // conductivity factors (SoilWaterParameterizations.jl:46-126)
+    int32_t viscosity_kind, impedance_kind;
+    FT gamma, T_ref_visc, Omega;
+
+    ColC<FT> uc; // column constants of the scalar parameters (host-computed)
+
+    // per-column overrides, device arrays [ncols] or nullptr
+    const FT* pc[PC_COUNT];
+    // boundary conditions [face][component]
+    int32_t bc_kind[2][2];
+    FT bc_value[2][2];
+    const FT* bc_pc[2][2];
+    int32_t consistent_bottom_sign;
+
+    uint32_t* status; // device word; bit 0 = non-finite tendency seen
+};
+
+// one FieldVector on the device: up to four planes [nlev][stride]
+template <typename FT>
+struct Planes {
+    FT* v[4];
+};
+
+} // namespace lh

@@ -1,0 +1,764 @@
+"""Host-side mirror of the LandHydrology.jl SoilModel API for the hot path.
+
+Julia is not available in the build image, so the host side above the C ABI is
+written in Python with the reference's names, argument meaning and error
+behaviour.  The Julia shim a maintainer would add is
+`julia/LandHydrologyHIP.jl` (text only); both are thin: all
+arithmetic happens in liblandhydro_hip.so on the GPU.
+
+Reference files mirrored (under the reference tree):
+  src/Domains/domain.jl                 Column, make_function_space
+  src/SoilModel/parameters.jl           SoilParams
+  src/SoilModel/SoilWaterParameterizations.jl  vanGenuchten, NoEffect, ...
+  src/SoilModel/models.jl               SoilModel, SoilHydrologyModel, ...
+  src/SoilModel/boundary_conditions.jl  NoBC, VerticalFlux, Dirichlet, FreeDrainage, ...
+  src/SoilModel/initial_conditions.jl   initialize_states
+  src/SoilModel/right_hand_side.jl      make_rhs, make_update_aux, coordinates
+  src/Simulations/simulation.jl         Simulation, step!, run!
+
+Build extension: `Column(..., ncolumns=N)` is an ensemble of N independent
+columns (the reference has exactly one); every field is then [ncolumns, nelements].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import _ffi as F
+
+Float32, Float64 = np.float32, np.float64
+
+# ------------------------------------------------------------------ Domains
+
+
+class Column:
+    """Column{FT}(zlim, nelements) -- src/Domains/domain.jl:12-33."""
+
+    def __init__(self, FT=Float64, *, zlim, nelements, ncolumns: int = 1):
+        self.FT = np.dtype(FT).type
+        F.dtype_code(self.FT)
+        zlim = (float(zlim[0]), float(zlim[1]))
+        if not zlim[0] < zlim[1]:                       # @assert zlim[1] < zlim[2], domain.jl:30
+            raise AssertionError("zlim[1] < zlim[2]")
+        self.zlim = (self.FT(zlim[0]), self.FT(zlim[1]))
+        self.nelements = int(nelements)
+        self.ncolumns = int(ncolumns)
+        if self.nelements < 1 or self.ncolumns < 1:
+            raise ValueError("nelements and ncolumns must be >= 1")
+        self.boundary_tags = ("bottom", "top")          # domain.jl:31
+
+    def ndims(self):                                    # domain.jl:35
+        return 1
+
+    def length(self):                                   # domain.jl:37
+        return self.zlim[1] - self.zlim[0]
+
+    def size(self):                                     # domain.jl:39
+        return self.length()
+
+    def __repr__(self):                                 # Base.show, domain.jl:41-49
+        return "[%0.1f, %0.1f]" % (self.zlim[0], self.zlim[1])
+
+
+def make_function_space(domain: Column):
+    """Centre and face z of the uniform column mesh (domain.jl:58-69).  The
+    rounding of the centres is the library's (lh_coordinates)."""
+    n = domain.nelements
+    lo, hi = np.longdouble(domain.zlim[0]), np.longdouble(domain.zlim[1])
+    zf = np.array([lo + (hi - lo) * k / n for k in range(n + 1)], dtype=np.longdouble)
+    zf = zf.astype(domain.FT)
+    zf[-1] = domain.zlim[1]
+    zc = ((zf[:-1] + zf[1:]) / domain.FT(2)).astype(domain.FT)
+    return zc, zf
+
+
+# --------------------------------------------------------------- parameters
+
+
+@dataclass
+class EarthParameterSet:
+    """The CLIMAParameters constants the soil model reads
+    (SoilHeatParameterizations.jl:12-13), CLIMAParameters 0.1 values.  They are
+    ABI inputs, never kernel literals."""
+    rho_cloud_liq: float = 1e3
+    rho_cloud_ice: float = 916.7
+    cp_l: float = 4181.0
+    cp_i: float = 2100.0
+    T_0: float = 273.16
+    LH_f0: float = 2.8344e6 - 2.5008e6   # LH_s0 - LH_v0
+    K_therm: float = 2.4e-2
+
+
+_SOIL_DEFAULTS = dict(nu=0.43, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.41,
+                      rho_c_ds=2700.0, kappa_solid=3.97, rho_p=2700.0, kappa_sat_unfrozen=1.72,
+                      kappa_sat_frozen=3.13, a=0.24, b=18.1, kappa_dry_parameter=0.053,
+                      z_0m=0.001, z_0s=0.001)
+# the reference's field names (parameters.jl:11-43) -> ASCII
+_SOIL_ALIASES = {"ν": "nu", "ν_ss_gravel": "nu_ss_gravel", "ν_ss_om": "nu_ss_om",
+                 "ν_ss_quartz": "nu_ss_quartz", "ρc_ds": "rho_c_ds", "κ_solid": "kappa_solid",
+                 "ρp": "rho_p", "κ_sat_unfrozen": "kappa_sat_unfrozen",
+                 "κ_sat_frozen": "kappa_sat_frozen", "κ_dry_parameter": "kappa_dry_parameter"}
+
+
+class SoilParams:
+    """SoilParams{FT}(; ν, S_s, ...) -- parameters.jl:11-43 (loam defaults).
+    `nu` and `S_s` may be arrays of ncolumns values (per-column soils)."""
+
+    def __init__(self, FT=Float64, **kw):
+        self.FT = np.dtype(FT).type
+        vals = dict(_SOIL_DEFAULTS)
+        for k, v in kw.items():
+            k = _SOIL_ALIASES.get(k, k)
+            if k not in vals:
+                raise TypeError(f"SoilParams has no field {k!r}")
+            vals[k] = v
+        self.__dict__.update(vals)
+
+    # reference spellings
+    ν = property(lambda s: s.nu)
+    ρc_ds = property(lambda s: s.rho_c_ds)
+
+
+class vanGenuchten:
+    """vanGenuchten{FT}(; n, α, Ksat, θr) -- SoilWaterParameterizations.jl:150-169.
+    Any field may be an array of ncolumns values (BASELINE config 5)."""
+
+    def __init__(self, FT=Float64, *, n=1.56, alpha=None, Ksat=2.9e-7, theta_r=None, **kw):
+        self.FT = np.dtype(FT).type
+        alpha = kw.pop("α", alpha)
+        theta_r = kw.pop("θr", theta_r)
+        if kw:
+            raise TypeError(f"vanGenuchten has no field(s) {sorted(kw)}")
+        self.n = n
+        self.alpha = 3.6 if alpha is None else alpha
+        self.theta_r = 0.0 if theta_r is None else theta_r
+        self.Ksat = Ksat
+
+    @property
+    def m(self):
+        n = np.asarray(self.n, dtype=self.FT)
+        return self.FT(1) - self.FT(1) / n
+
+    α = property(lambda s: s.alpha)
+    θr = property(lambda s: s.theta_r)
+
+
+class NoEffect:
+    """SoilWaterParameterizations.jl:38"""
+
+    def __init__(self, FT=Float64):
+        self.FT = FT
+
+
+class TemperatureDependentViscosity:
+    """SoilWaterParameterizations.jl:46-52"""
+
+    def __init__(self, FT=Float64, *, gamma=2.64e-2, T_ref=288.0, **kw):
+        self.FT = FT
+        self.gamma = kw.pop("γ", gamma)
+        self.T_ref = T_ref
+        if kw:
+            raise TypeError(f"unknown field(s) {sorted(kw)}")
+
+
+class IceImpedance:
+    """SoilWaterParameterizations.jl:62-65"""
+
+    def __init__(self, FT=Float64, *, Omega=7.0, **kw):
+        self.FT = FT
+        self.Omega = kw.pop("Ω", Omega)
+        if kw:
+            raise TypeError(f"unknown field(s) {sorted(kw)}")
+
+
+# ------------------------------------------------------------ component models
+
+
+class SoilEnergyModel:
+    """models.jl:17"""
+
+
+class SoilHydrologyModel:
+    """models.jl:28-33"""
+
+    def __init__(self, FT=Float64, *, hydraulic_model=None, viscosity_factor=None,
+                 impedance_factor=None):
+        self.FT = np.dtype(FT).type
+        self.hydraulic_model = hydraulic_model if hydraulic_model is not None else vanGenuchten(FT)
+        self.viscosity_factor = viscosity_factor if viscosity_factor is not None else NoEffect(FT)
+        self.impedance_factor = impedance_factor if impedance_factor is not None else NoEffect(FT)
+        if not isinstance(self.viscosity_factor, (NoEffect, TemperatureDependentViscosity)):
+            raise TypeError("viscosity_factor must be NoEffect or TemperatureDependentViscosity")
+        if not isinstance(self.impedance_factor, (NoEffect, IceImpedance)):
+            raise TypeError("impedance_factor must be NoEffect or IceImpedance")
+
+
+class PrescribedTemperatureModel:
+    """models.jl:51-54; default profile 288 K."""
+
+    def __init__(self, T_profile: Optional[Callable] = None):
+        self.is_default = T_profile is None
+        self.T_profile = T_profile if T_profile is not None else (lambda z, t: 288.0 + 0.0 * z)
+
+
+class PrescribedHydrologyModel:
+    """models.jl:73-78; defaults: totally dry soil."""
+
+    def __init__(self, vartheta_l_profile: Optional[Callable] = None,
+                 theta_i_profile: Optional[Callable] = None, **kw):
+        vartheta_l_profile = kw.pop("ϑ_l_profile", kw.pop("θ_l_profile", vartheta_l_profile))
+        theta_i_profile = kw.pop("θ_i_profile", theta_i_profile)
+        if kw:
+            raise TypeError(f"unknown field(s) {sorted(kw)}")
+        self.vartheta_l_profile = vartheta_l_profile or (lambda z, t: 0.0 * z)
+        self.theta_i_profile = theta_i_profile or (lambda z, t: 0.0 * z)
+
+
+# --------------------------------------------------------- boundary conditions
+
+
+class NoBC:
+    """boundary_conditions.jl:27"""
+
+
+class VerticalFlux:
+    """boundary_conditions.jl:43-46; positive = aligned with z-hat.  A scalar, or
+    an array of ncolumns values."""
+
+    def __init__(self, flux):
+        self.flux = flux
+
+
+class Dirichlet:
+    """boundary_conditions.jl:61-64; state_value is t -> value (scalar or
+    per-column array); a number is accepted as a constant."""
+
+    def __init__(self, state_value):
+        self.state_value = state_value if callable(state_value) else (lambda t, v=state_value: v)
+
+
+class FreeDrainage:
+    """boundary_conditions.jl:77"""
+
+
+class SoilComponentBC:
+    """boundary_conditions.jl:95-101"""
+
+    def __init__(self, *, energy=None, hydrology=None):
+        self.energy = energy if energy is not None else NoBC()
+        self.hydrology = hydrology if hydrology is not None else NoBC()
+
+
+class PrescribedAtmosForcing:
+    """boundary_conditions.jl:119-132 -- outside the hot path."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError(
+            "PrescribedAtmosForcing (Monin-Obukhov surface fluxes) is out of scope of the "
+            "accelerated path; see DESIGN.md")
+
+
+class SoilColumnBC:
+    """boundary_conditions.jl:144-161"""
+
+    def __init__(self, *, top=None, bottom=None):
+        self.top = top if top is not None else SoilComponentBC()
+        self.bottom = bottom if bottom is not None else SoilComponentBC()
+        if not isinstance(self.bottom, SoilComponentBC) or not isinstance(self.top, SoilComponentBC):
+            raise TypeError("top/bottom must be SoilComponentBC")
+
+
+_BC_KIND = {NoBC: F.LH_BC_NONE, VerticalFlux: F.LH_BC_FLUX, Dirichlet: F.LH_BC_DIRICHLET,
+            FreeDrainage: F.LH_BC_FREE_DRAINAGE}
+
+# ------------------------------------------------------------------- states
+
+_VAR = {"ϑ_l": 0, "θ_l": 0, "vartheta_l": 0, "θ_i": 1, "theta_i": 1, "ρe_int": 2, "rhoe_int": 2,
+        "T": 3}
+_NAMES = ["ϑ_l", "θ_i", "ρe_int", "T"]
+
+
+class _Namespace:
+    """`Y.soil` -- attribute access downloads the field as [ncolumns, nelements]."""
+
+    def __init__(self, fv):
+        object.__setattr__(self, "_fv", fv)
+
+    def __getattr__(self, name):
+        if name not in _VAR:
+            raise AttributeError(name)
+        return self._fv.get(name)
+
+    def __setattr__(self, name, value):
+        self._fv.set(name, value)
+
+
+class FieldVector:
+    """Device-resident analogue of Fields.FieldVector(; soil = (...)): one
+    lh_state.  `fv.soil.ϑ_l` downloads, `fv.soil.ϑ_l = a` uploads (host arrays are
+    level-fastest [ncolumns, nelements] like parent(field); a 1-D array of
+    nelements is broadcast over columns)."""
+
+    def __init__(self, model: "SoilModel", mask: int, zc=None):
+        self.model = model
+        self._be = model._backend()
+        self.mask = mask
+        h = C.c_void_p()
+        F.check(F.lib().lh_state_create(self._be.ctx, mask, C.byref(h)), self._be.ctx)
+        self.handle = h
+        self.zc = zc
+        self.soil = _Namespace(self)
+        setattr(self, model.name, self.soil)
+
+    def __del__(self):
+        try:
+            if self.handle and self._be.ctx:
+                F.lib().lh_state_destroy(self._be.ctx, self.handle)
+        except Exception:
+            pass
+
+    @property
+    def names(self):
+        return [n for i, n in enumerate(_NAMES) if self.mask & (1 << i)]
+
+    def get(self, name) -> np.ndarray:
+        d = self.model.domain
+        out = np.empty((d.ncolumns, d.nelements), dtype=d.FT)
+        F.check(F.lib().lh_download(self._be.ctx, self.handle, _VAR[name], out.ctypes.data, 1,
+                                    d.nelements), self._be.ctx)
+        return out
+
+    def set(self, name, value):
+        d = self.model.domain
+        a = np.asarray(value, dtype=d.FT)
+        if a.ndim == 0:
+            F.check(F.lib().lh_state_fill(self._be.ctx, self.handle, _VAR[name], float(a)),
+                    self._be.ctx)
+            return
+        if a.ndim == 1:
+            a = np.broadcast_to(a, (d.ncolumns, d.nelements))
+        if a.shape != (d.ncolumns, d.nelements):
+            raise ValueError(f"expected shape {(d.ncolumns, d.nelements)}, got {a.shape}")
+        a = np.ascontiguousarray(a)
+        F.check(F.lib().lh_upload(self._be.ctx, self.handle, _VAR[name], a.ctypes.data, 1,
+                                  d.nelements), self._be.ctx)
+
+    def similar(self) -> "FieldVector":
+        return FieldVector(self.model, self.mask, self.zc)
+
+    def copy(self) -> "FieldVector":
+        o = self.similar()
+        F.check(F.lib().lh_state_copy(self._be.ctx, o.handle, self.handle), self._be.ctx)
+        return o
+
+    def device_ptr(self, name):
+        p, ls, cs = C.c_void_p(), C.c_int64(), C.c_int64()
+        F.check(F.lib().lh_state_device_ptr(self._be.ctx, self.handle, _VAR[name], C.byref(p),
+                                            C.byref(ls), C.byref(cs)), self._be.ctx)
+        return p.value, ls.value, cs.value
+
+
+# -------------------------------------------------------------------- model
+
+
+class _Backend:
+    """One lh_ctx: the device-side image of a SoilModel."""
+
+    def __init__(self, model: "SoilModel", stream=None, device=-1):
+        d = model.domain
+        L = F.lib()
+        em, hm = model.energy_model, model.hydrology_model
+        if isinstance(em, SoilEnergyModel) and isinstance(hm, SoilHydrologyModel):
+            kind = F.LH_MODEL_COUPLED
+        elif isinstance(em, SoilEnergyModel) and isinstance(hm, PrescribedHydrologyModel):
+            kind = F.LH_MODEL_HEAT
+        elif isinstance(em, PrescribedTemperatureModel) and isinstance(hm, SoilHydrologyModel):
+            kind = F.LH_MODEL_RICHARDS
+        else:
+            kind = None   # prescribed/prescribed: empty RHS (right_hand_side.jl:103-112)
+        self.kind = kind
+        self.ctx = None
+        self._keep = []
+        if kind is None:
+            return
+        cfg = F.lh_config(d.ncolumns, d.nelements, F.dtype_code(d.FT), float(d.zlim[0]),
+                          float(d.zlim[1]), kind, device, stream)
+        ctx = C.c_void_p()
+        F.check(L.lh_create(C.byref(ctx), C.byref(cfg)), None)
+        self.ctx = ctx
+        ep = model.earth_param_set
+        if ep is not None and kind != F.LH_MODEL_RICHARDS:
+            e = F.lh_earth_params(ep.rho_cloud_liq, ep.rho_cloud_ice, ep.cp_l, ep.cp_i, ep.T_0,
+                                  ep.LH_f0, ep.K_therm)
+            F.check(L.lh_set_earth_params(ctx, C.byref(e)), ctx)
+        sp = model.soil_param_set
+        scal = {}
+        for k in F.lh_soil_params._fields_:
+            v = getattr(sp, k[0])
+            scal[k[0]] = self._scalar_or_percol(k[0], v, d)
+        s = F.lh_soil_params(**scal)
+        F.check(L.lh_set_soil_params(ctx, C.byref(s)), ctx)
+        if isinstance(hm, SoilHydrologyModel):
+            vg = hm.hydraulic_model
+            v = F.lh_vg_params(self._scalar_or_percol("vg_n", vg.n, d),
+                               self._scalar_or_percol("vg_alpha", vg.alpha, d),
+                               self._scalar_or_percol("vg_theta_r", vg.theta_r, d),
+                               self._scalar_or_percol("vg_Ksat", vg.Ksat, d))
+            F.check(L.lh_set_vg_params(ctx, C.byref(v)), ctx)
+            vf, imf = hm.viscosity_factor, hm.impedance_factor
+            vk = isinstance(vf, TemperatureDependentViscosity)
+            ik = isinstance(imf, IceImpedance)
+            F.check(L.lh_set_conductivity_factors(
+                ctx, int(vk), vf.gamma if vk else 2.64e-2, vf.T_ref if vk else 288.0, int(ik),
+                imf.Omega if ik else 7.0), ctx)
+        self.time_dependent_bc = False
+        self.set_bcs(model, 0.0)
+
+    def _scalar_or_percol(self, key, v, d):
+        a = np.asarray(v, dtype=np.float64)
+        if a.ndim == 0:
+            return float(a)
+        if key not in F.LH_PC:
+            raise ValueError(f"{key} cannot vary per column")
+        if a.shape != (d.ncolumns,):
+            raise ValueError(f"{key}: expected {d.ncolumns} per-column values, got shape {a.shape}")
+        a = np.ascontiguousarray(a)
+        F.check(F.lib().lh_set_percol_param(self.ctx, F.LH_PC[key],
+                                            a.ctypes.data_as(C.POINTER(C.c_double))), self.ctx)
+        return float(a[0])
+
+    def bc_values(self, model, t):
+        """Evaluate the BC closures at time t -> {(face, comp): (kind, value)}."""
+        out = {}
+        for face, tag in ((F.LH_FACE_BOTTOM, "bottom"), (F.LH_FACE_TOP, "top")):
+            fbc = getattr(model.boundary_conditions, tag)
+            for comp, cname in ((F.LH_COMP_ENERGY, "energy"), (F.LH_COMP_HYDROLOGY, "hydrology")):
+                bc = getattr(fbc, cname)
+                kind = _BC_KIND.get(type(bc))
+                if kind is None:
+                    raise TypeError(f"unsupported boundary condition {type(bc).__name__}")
+                val = 0.0
+                if kind == F.LH_BC_FLUX:
+                    val = bc.flux
+                elif kind == F.LH_BC_DIRICHLET:
+                    val = bc.state_value(t)
+                out[(face, comp)] = (kind, val)
+        return out
+
+    def set_bcs(self, model, t):
+        if model.boundary_conditions is None:
+            return
+        L = F.lib()
+        d = model.domain
+        for (face, comp), (kind, val) in self.bc_values(model, t).items():
+            a = np.asarray(val, dtype=np.float64)
+            if a.ndim == 0:
+                F.check(L.lh_set_bc(self.ctx, face, comp, kind, float(a), None), self.ctx)
+            else:
+                if a.shape != (d.ncolumns,):
+                    raise ValueError("per-column boundary values must have ncolumns entries")
+                a = np.ascontiguousarray(a)
+                F.check(L.lh_set_bc(self.ctx, face, comp, kind, float(a[0]),
+                                    a.ctypes.data_as(C.POINTER(C.c_double))), self.ctx)
+
+    def close(self):
+        if self.ctx:
+            F.lib().lh_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SoilModel:
+    """SoilModel(FT; domain, energy_model, hydrology_model, boundary_conditions,
+    soil_param_set, earth_param_set, name) -- models.jl:90-135."""
+
+    def __init__(self, FT=Float64, *, domain, energy_model, hydrology_model, boundary_conditions,
+                 soil_param_set=None, earth_param_set, name="soil", stream=None, device=-1):
+        self.FT = np.dtype(FT).type
+        if np.dtype(domain.FT) != np.dtype(self.FT):
+            raise TypeError("domain FT differs from the model FT")   # AbstractVerticalDomain{FT}
+        self.domain = domain
+        self.energy_model = energy_model
+        self.hydrology_model = hydrology_model
+        self.boundary_conditions = boundary_conditions
+        self.soil_param_set = soil_param_set if soil_param_set is not None else SoilParams(FT)
+        self.earth_param_set = earth_param_set
+        self.name = name
+        self._stream, self._device = stream, device
+        self._be = None
+
+    def _backend(self) -> _Backend:
+        if self._be is None:
+            self._be = _Backend(self, self._stream, self._device)
+        return self._be
+
+    def close(self):
+        if self._be is not None:
+            self._be.close()
+
+
+def coordinates(model: SoilModel) -> np.ndarray:
+    """coordinates(cs) (right_hand_side.jl:7-8): cell-centre z as the library
+    holds them."""
+    be = model._backend()
+    n = model.domain.nelements
+    if be.ctx is None:
+        return make_function_space(model.domain)[0]
+    z = np.empty(n, dtype=np.float64)
+    F.check(F.lib().lh_coordinates(be.ctx, z.ctypes.data_as(C.POINTER(C.c_double))), be.ctx)
+    return z.astype(model.domain.FT)
+
+
+def _prognostic_mask(kind):
+    return {F.LH_MODEL_RICHARDS: 0b0011, F.LH_MODEL_HEAT: 0b0100, F.LH_MODEL_COUPLED: 0b0111}[kind]
+
+
+def _aux_mask(kind, model):
+    """Planes of Ya the DEVICE reads: (ϑ_l, θ_i) for a prescribed hydrology; T for
+    a prescribed temperature only when a viscosity factor consumes it
+    (right_hand_side.jl:160).  Otherwise Ya stays a host object."""
+    if kind == F.LH_MODEL_HEAT:
+        return 0b0011
+    if kind == F.LH_MODEL_RICHARDS and isinstance(model.hydrology_model.viscosity_factor,
+                                                  TemperatureDependentViscosity):
+        return 0b1000
+    return 0
+
+
+class _HostAux:
+    """Ya for models whose aux fields never reach the device (or prescribed /
+    prescribed models): plain host arrays with the same attribute access."""
+
+    def __init__(self, zc, fields):
+        self.zc = zc
+        self.soil = type("soil", (), {})()
+        for k, v in fields.items():
+            setattr(self.soil, k, v)
+
+
+def make_update_aux(component_model, model: Optional[SoilModel] = None):
+    """make_update_aux (right_hand_side.jl:54-96): returns update_aux!(Ya, t),
+    which overwrites the prescribed fields of Ya with the closures at time t."""
+    if isinstance(component_model, PrescribedTemperatureModel):
+        def update_aux(Ya, t):
+            z = np.asarray(Ya.zc)
+            Ya.soil.T = np.asarray(component_model.T_profile(z, t) + 0.0 * z)
+            return Ya
+        return update_aux
+    if isinstance(component_model, PrescribedHydrologyModel):
+        def update_aux(Ya, t):
+            z = np.asarray(Ya.zc)
+            Ya.soil.θ_l = np.asarray(component_model.vartheta_l_profile(z, t) + 0.0 * z)
+            Ya.soil.θ_i = np.asarray(component_model.theta_i_profile(z, t) + 0.0 * z)
+            return Ya
+        return update_aux
+
+    def update_aux(Ya, t):      # models that add no auxiliary variables (:91-96)
+        return None
+    return update_aux
+
+
+def initialize_states(model: SoilModel, f: Callable, t0):
+    """initialize_states(model, f, t0) -> (Y, Ya) (initial_conditions.jl:101-107).
+    `f(z, model)` returns a dict (NamedTuple) of the prognostic variables at the
+    centre coordinate z; it is called once with the vector of nelements centres
+    (scalars, [nelements] or [ncolumns, nelements] values are accepted), or per
+    level if it cannot take arrays."""
+    be = model._backend()
+    d = model.domain
+    zc = coordinates(model)
+    if be.kind is None:
+        fields = {}
+        if isinstance(model.energy_model, PrescribedTemperatureModel):
+            fields["T"] = np.asarray(model.energy_model.T_profile(zc, t0) + 0.0 * zc)
+        if isinstance(model.hydrology_model, PrescribedHydrologyModel):
+            fields["θ_l"] = np.asarray(model.hydrology_model.vartheta_l_profile(zc, t0) + 0 * zc)
+            fields["θ_i"] = np.asarray(model.hydrology_model.theta_i_profile(zc, t0) + 0 * zc)
+        return {}, _HostAux(zc, fields)
+    try:
+        ic = f(zc, model)
+        ic = {k: np.asarray(v) for k, v in ic.items()}
+    except (TypeError, ValueError):
+        per = [f(d.FT(z), model) for z in zc]
+        ic = {k: np.array([p[k] for p in per]) for k in per[0]}
+    Y = FieldVector(model, _prognostic_mask(be.kind), zc)
+    want = set(Y.names)
+    got = {_NAMES[_VAR[k]] for k in ic}
+    if got != want:
+        raise KeyError(f"initial condition must provide {sorted(want)}, got {sorted(ic)}")
+    for k, v in ic.items():
+        if v.ndim == 0:
+            v = np.full(d.nelements, v)
+        Y.set(k, v)
+    am = _aux_mask(be.kind, model)
+    Ya = FieldVector(model, am, zc) if am else _HostAux(zc, {})
+    make_update_aux(model.energy_model)(Ya, t0)
+    make_update_aux(model.hydrology_model)(Ya, t0)
+    return Y, Ya
+
+
+def default_initial_conditions(model: SoilModel):
+    """models.jl:147-166: isothermal soil at T0 = 273.16, no ice, ϑ_l = ν/2; only
+    for SoilEnergyModel + SoilHydrologyModel."""
+    if not (isinstance(model.energy_model, SoilEnergyModel)
+            and isinstance(model.hydrology_model, SoilHydrologyModel)):
+        raise RuntimeError("No default IC exist for this type of soil model.")
+    FT = model.FT
+    ep, sp = model.earth_param_set, model.soil_param_set
+
+    def ic(z, m):
+        T = FT(273.16)
+        theta_i = FT(0.0)
+        theta_l = FT(0.5) * FT(sp.nu)
+        # volumetric_heat_capacity / volumetric_internal_energy with FT rounding
+        rho_i, rho_l = FT(ep.rho_cloud_ice), FT(ep.rho_cloud_liq)
+        rhocp_i = FT(ep.cp_i * float(rho_i))
+        rhocp_l = FT(ep.cp_l * float(rho_l))
+        rho_c_s = FT(sp.rho_c_ds) + theta_l * rhocp_l + theta_i * rhocp_i
+        rhoe = rho_c_s * (T - FT(ep.T_0)) - theta_i * rho_i * FT(ep.LH_f0)
+        return {"ϑ_l": theta_l, "θ_i": theta_i, "ρe_int": rhoe}
+
+    return initialize_states(model, ic, FT(0.0))
+
+
+def make_rhs(model: SoilModel):
+    """make_rhs(model) -> rhs!(dY, Y, Ya, t) (right_hand_side.jl:33-44).  In place
+    on dY, returns dY.  Everything numerical happens in lh_rhs on the GPU."""
+    be = model._backend()
+    if be.kind is None:
+        def rhs_empty(dY, Y, Ya, t):   # right_hand_side.jl:103-112
+            make_update_aux(model.energy_model)(Ya, t)
+            make_update_aux(model.hydrology_model)(Ya, t)
+            return dY
+        return rhs_empty
+    update_en = make_update_aux(model.energy_model)
+    update_hy = make_update_aux(model.hydrology_model)
+    L = F.lib()
+    needs_aux = bool(_aux_mask(be.kind, model))
+
+    def rhs(dY, Y, Ya, t):
+        if needs_aux:
+            update_en(Ya, t)
+            update_hy(Ya, t)
+        be.set_bcs(model, t)
+        ya = Ya.handle if isinstance(Ya, FieldVector) else None
+        F.check(L.lh_rhs(be.ctx, float(t), Y.handle, ya, dY.handle), be.ctx)
+        return dY
+
+    return rhs
+
+
+# --------------------------------------------------------------- Simulations
+
+
+class SSPRK33:
+    """OrdinaryDiffEq.SSPRK33 marker (the only stepper the reference's tests use)."""
+
+
+class _Solution:
+    def __init__(self):
+        self.t = []
+        self.u = []
+
+
+class _Integrator:
+    def __init__(self, model, Y, Ya, t0, tf, dt, saveat):
+        self.model, self.u, self.p = model, Y, Ya
+        self.t, self.tf, self.dt = float(t0), float(tf), float(dt)
+        self.saveat = saveat
+        self.sol = _Solution()
+        self._nsteps_done = 0
+        self._save()
+
+    def _save(self):
+        self.sol.t.append(self.t)
+        self.sol.u.append({n: self.u.get(n) for n in self.u.names})
+
+
+class Simulation:
+    """Simulation(model, method; Y_init, dt, tspan, Ya_init, saveat, ...)
+    (simulation.jl:34-73).  Stepping is lh_step_ssprk33: the whole SSPRK33 step
+    runs on the device; Dirichlet closures are evaluated on the host at the stage
+    times t, t+dt, t+dt/2 and passed as numbers."""
+
+    def __init__(self, model, method, *, Y_init, dt, tspan, Ya_init, callbacks=None, saveat=None,
+                 **kwargs):
+        if not isinstance(method, SSPRK33):
+            raise NotImplementedError("only SSPRK33 is provided on the device")
+        if Y_init is None:
+            # simulation.jl:50 references an undefined variable here:
+            # the reference cannot run this branch either.
+            raise NameError("soil_model not defined")
+        self.model = model
+        self.callbacks = callbacks
+        self.integrator = _Integrator(model, Y_init, Ya_init, tspan[0], tspan[1], dt, saveat)
+
+
+def _time_dependent(model):
+    bcs = model.boundary_conditions
+    for tag in ("top", "bottom"):
+        for c in ("energy", "hydrology"):
+            if isinstance(getattr(getattr(bcs, tag), c), Dirichlet):
+                return True
+    return False
+
+
+def _advance(sim: Simulation, nsteps: int):
+    it = sim.integrator
+    model = sim.model
+    be = model._backend()
+    L = F.lib()
+    ya = it.p.handle if isinstance(it.p, FieldVector) else None
+    if nsteps <= 0:
+        return
+    bcv = None
+    if _time_dependent(model):
+        t = it.t + it.dt * np.arange(nsteps)
+        vals = np.zeros((nsteps, 3, 2, 2))
+        base = be.bc_values(model, it.t)
+        for (f, c), (kind, v) in base.items():
+            if np.ndim(v) == 0:
+                vals[:, :, f, c] = float(v)
+        for si, off in enumerate((0.0, it.dt, it.dt / 2)):
+            for k in range(nsteps):
+                for (f, c), (kind, v) in be.bc_values(model, t[k] + off).items():
+                    if kind == F.LH_BC_DIRICHLET and np.ndim(v) == 0:
+                        vals[k, si, f, c] = float(v)
+        bcv = np.ascontiguousarray(vals)
+    be.set_bcs(model, it.t)
+    F.check(L.lh_step_ssprk33(be.ctx, it.u.handle, ya, it.t, it.dt, nsteps,
+                              bcv.ctypes.data_as(C.POINTER(C.c_double)) if bcv is not None
+                              else None), be.ctx)
+    it._nsteps_done += nsteps
+    it.t = it.t + nsteps * it.dt
+
+
+def step(sim: Simulation):
+    """step!(simulation) (simulation.jl:79-80)."""
+    _advance(sim, 1)
+    return None
+
+
+def run(sim: Simulation):
+    """run!(simulation) (simulation.jl:86-87): integrate to tspan[2], saving
+    every `saveat` like DiffEq's saveat."""
+    it = sim.integrator
+    total = int(round((it.tf - it.t) / it.dt))
+    chunk = total
+    if it.saveat:
+        chunk = max(1, int(round(it.saveat / it.dt)))
+    done = 0
+    while done < total:
+        n = min(chunk, total - done)
+        _advance(sim, n)
+        done += n
+        it._save()
+    return it.sol

@@ -1,0 +1,102 @@
+"""CPU-side checks of the C-ABI boundary (no GPU compute): the library builds,
+loads, exports every symbol include/landhydro.h declares, and fails loudly --
+never silently -- when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    g.build() if not os.path.exists(os.path.join(g.PKG_DIR, "lib", "liblandhydro_hip.so")) else None
+    return g.load_package()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "landhydro.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(pkg):
+    L = pkg._ffi.lib()
+    names = declared_symbols()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in landhydro.h but not exported"
+    # and the binding covers exactly the declared set
+    assert sorted(pkg._ffi.SIGNATURES) == names
+
+
+def test_version(pkg):
+    assert pkg._ffi.lib().lh_version() == 1
+
+
+def test_create_rejects_bad_arguments(pkg):
+    F = pkg._ffi
+    L = F.lib()
+    ctx = C.c_void_p()
+    bad = [
+        F.lh_config(0, 64, F.LH_F64, -1.0, 0.0, F.LH_MODEL_RICHARDS, -1, None),   # ncols
+        F.lh_config(10, 0, F.LH_F64, -1.0, 0.0, F.LH_MODEL_RICHARDS, -1, None),   # nlev
+        F.lh_config(10, 64, F.LH_F64, 0.0, -1.0, F.LH_MODEL_RICHARDS, -1, None),  # zlim order
+        F.lh_config(10, 64, 7, -1.0, 0.0, F.LH_MODEL_RICHARDS, -1, None),         # dtype
+        F.lh_config(10, 64, F.LH_F64, -1.0, 0.0, 9, -1, None),                    # model
+    ]
+    for cfg in bad:
+        rc = L.lh_create(C.byref(ctx), C.byref(cfg))
+        assert rc == F.LH_EINVAL and not ctx.value
+        assert L.lh_last_error(None)
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    F = pkg._ffi
+    ctx = C.c_void_p()
+    cfg = F.lh_config(10, 64, F.LH_F64, -1.0, 0.0, F.LH_MODEL_RICHARDS, -1, None)
+    rc = F.lib().lh_create(C.byref(ctx), C.byref(cfg))
+    assert rc == F.LH_ENODEVICE and not ctx.value
+    assert b"no CPU path" in F.lib().lh_last_error(None)
+    with pytest.raises(F.LandHydroError):
+        F.check(rc, None)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under landhydrology.jl_amd/ may
+    reference it (SURVEY/DESIGN: a product path through the oracle voids parity)."""
+    for dirpath, _, files in os.walk(g.PKG_DIR):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".jl")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for line in text.splitlines():
+                    code = line.split("//")[0].split("#")[0]
+                    assert "oracle_py" not in code and "lh_oracle" not in code and "liblh_oracle" not in code, (
+                        f"{f}: product code references the oracle: {line.strip()}")
+
+
+def test_host_mirror_domain_and_errors(pkg):
+    """test/test_domains.jl:13-32 through the host mirror (no device needed)."""
+    import numpy as np
+    for FT in (np.float32, np.float64):
+        d = pkg.Column(FT, zlim=(0.0, 1.0), nelements=2)
+        assert d.zlim == (0.0, 1.0) and d.nelements == 2
+        assert d.ndims() == 1
+        assert pkg.Column(FT, zlim=(1.0, 2.0), nelements=2).length() == 1.0
+        assert pkg.Column(FT, zlim=(1.0, 4.0), nelements=2).size() == 3.0
+        assert repr(d) == "[0.0, 1.0]"
+        assert d.FT is FT
+    with pytest.raises(AssertionError):
+        pkg.Column(np.float64, zlim=(1.0, 0.0), nelements=2)     # domain.jl:30
+    zc, zf = pkg.make_function_space(pkg.Column(np.float64, zlim=(-2.0, 0.0), nelements=20))
+    want = np.array([(-195 + 10 * i) / 100 for i in range(20)])
+    assert np.allclose(zc, want, rtol=0, atol=4.5e-16)           # coupled.jl:198
+    with pytest.raises(NotImplementedError):
+        pkg.PrescribedAtmosForcing(u_atm=1.0)

@@ -1,0 +1,123 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs (tests/parity_cases.py).
+
+Tolerance: `tendency_tolerance` propagates Cw*eps(FT) through the cancelling
+sub-expressions of the closures and the flux differences (see parity_cases.py).
+Cw = 4 for both working types: i.e. the two implementations may differ by a few
+units of rounding per operation, nothing more.  d(theta_i) must be exactly 0.
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+CW = 4.0
+CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128",
+         "c3_coupled_f32", "c3_coupled_f64", "c5_percol_f64", "heat_dirichlet_f64",
+         "heat_dirichlet_f32", "mixed_factors_f64", "mixed_factors_f32", "richards_viscosity_f64",
+         "single_cell_f64"]
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("math", ["fast", "libm"])
+def test_rhs_matches_oracle(name, math):
+    case = pc.make_case(name)
+    F = pc._pkg()._ffi
+    mode = F.LH_MATH_FAST if math == "fast" else F.LH_MATH_LIBM
+    got = pc.run_gpu_rhs(case, mode)
+    want = pc.run_oracle_rhs(case)
+    pc.assert_tendencies_close(case, got, want, CW, label=f"[{math}]")
+
+
+@pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_factors_f64",
+                                  "mixed_factors_f32", "c5_percol_f64"])
+def test_closures_match_oracle(name):
+    """K, psi, kappa, T of the pointwise stage (lh_diagnostics) against the oracle."""
+    case = pc.make_case(name)
+    got = pc.run_gpu_diagnostics(case)
+    want = pc.O.diagnostics(case.om, case.vl, case.ti, case.rhoe, case.T_aux)
+    tol = pc.closure_tolerances(case, want, CW)
+    for k in ("K", "psi", "T", "kappa"):
+        if case.om.model == pc.O.MODEL_RICHARDS and k in ("T", "kappa"):
+            continue
+        err = np.abs(got[k].astype(np.float64) - want[k].astype(np.float64))
+        assert np.all(err <= tol[k]), (k, float(np.max(err / tol[k])))
+
+
+def test_ragged_and_tiny_batches():
+    """Column counts that are not multiples of the wave/block size."""
+    for ncols in (1, 2, 63, 64, 65, 257, 1023):
+        for name in ("c2_richards_f64", "c3_coupled_f32"):
+            case = pc.make_case(name, ncols=ncols)
+            got = pc.run_gpu_rhs(case)
+            want = pc.run_oracle_rhs(case)
+            pc.assert_tendencies_close(case, got, want, CW, label=f"[ncols={ncols}]")
+
+
+def test_upload_download_roundtrip_layouts():
+    """Both host layouts (level-fastest parent(field) and column-fastest planes),
+    with padding, round-trip bit-exactly."""
+    case = pc.make_case("c2_richards_f64", ncols=333)
+    rng = np.random.default_rng(1)
+    n = case.om.nlev
+    with pc.GpuModel(case) as g:
+        F = g.F
+        st = g.state(0)
+        a = rng.standard_normal((333, n))
+        g.upload(st, F.LH_VAR_VARTHETA_L, a)                      # level-fastest
+        assert np.array_equal(g.download(st, F.LH_VAR_VARTHETA_L), a)
+        b = np.asfortranarray(rng.standard_normal((333, n)))       # column-fastest
+        g.upload(st, F.LH_VAR_THETA_I, b)
+        out = np.empty((n, 400)).T[:333]                           # column-fastest with padding
+        g.download(st, F.LH_VAR_THETA_I, out)
+        assert np.array_equal(out, b)
+        wide = np.zeros((333, n + 5))                              # level-fastest with gaps
+        view = wide[:, :n]
+        view[...] = a
+        g.upload(st, F.LH_VAR_VARTHETA_L, view)
+        back = np.full((333, n + 5), -7.0)
+        g.download(st, F.LH_VAR_VARTHETA_L, back[:, :n])
+        assert np.array_equal(back[:, :n], a) and np.all(back[:, n:] == -7.0)
+
+
+def test_invalid_models_raise_like_the_reference():
+    F = pc._pkg()._ffi
+    case = pc.make_case("c2_richards_f64", ncols=8)
+    case.om.bc = {}                                  # NoBC on a dynamic component
+    with pc.GpuModel(case) as g:
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        with pytest.raises(F.ModelError):
+            g.rhs(Y, Ya, dY)
+    case = pc.make_case("c2_richards_f64", ncols=8)
+    case.om.bc[(pc.O.FACE_TOP, pc.O.COMP_ENERGY)] = (pc.O.BC_DIRICHLET, 280.0)
+    with pc.GpuModel(case) as g:
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        with pytest.raises(F.ModelError):
+            g.rhs(Y, Ya, dY)
+        # a state without the needed planes
+        bad = g.state(0b0100)
+        with pytest.raises(F.LandHydroError):
+            g.rhs(Y, Ya, bad)
+
+
+def test_nonfinite_flag():
+    case = pc.make_case("c2_richards_f64", ncols=100)
+    case.vl[7, 3] = np.nan
+    with pc.GpuModel(case) as g:
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        g.rhs(Y, Ya, dY)
+        assert g.status() & 1
+        assert g.status() == 0      # cleared by the read
+
+
+def test_bottom_sign_flag():
+    case = pc.make_case("c1_dirichlet_f64")
+    case.om.consistent_bottom_sign = True
+    got = pc.run_gpu_rhs(case)
+    want = pc.run_oracle_rhs(case)
+    pc.assert_tendencies_close(case, got, want, CW)
