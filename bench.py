@@ -115,8 +115,12 @@ def main():
 
     case = build_case(a.workload, a.ncols, rank * a.ncols)
     nlev = case.om.nlev
-    stream = torch.cuda.current_stream().cuda_stream
-    gm = pc.GpuModel(case, stream=stream)
+    # one explicit HIP stream shared by torch (events, collectives' stream
+    # dependencies) and the library: torch's default stream is the NULL handle,
+    # which the C ABI reads as "create your own"
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    gm = pc.GpuModel(case, stream=tstream.cuda_stream)
     Y, Ya = gm.prognostic_and_aux()
     dY = gm.state(0)
     L, ctx = gm.L, gm.ctx
@@ -156,13 +160,12 @@ def main():
     # around a back-to-back run of the dominant kernel alone (no collectives)
     kreps = max(20, min(a.steps, 200))
     torch.cuda.synchronize()
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
+    F.check(L.lh_timer_start(ctx), ctx)          # hipEventRecord on the launch stream
     for _ in range(kreps):
         F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
-    k1.record()
-    torch.cuda.synchronize()
-    kern_ms = k0.elapsed_time(k1) / kreps
+    ms = C.c_float()
+    F.check(L.lh_timer_stop(ctx, C.byref(ms)), ctx)
+    kern_ms = ms.value / kreps
 
     cells = a.ncols * nlev
     bytes_per_cell = WORKLOADS[a.workload][1]

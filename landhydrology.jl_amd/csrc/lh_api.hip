@@ -53,6 +53,7 @@ struct lh_ctx {
     void* d_bc_pc[2][2] = {};          // FT[ncols] or null
     uint32_t* d_status = nullptr;
     void* d_dt = nullptr;              // FT scratch for lh_stable_dt
+    double* d_math_tab = nullptr;      // log2/exp2 tables of MathFast<double>
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int math = MATH_FAST;
@@ -160,6 +161,8 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_m = FT(1) / u.m;
     u.alpha_pnn = host_pow<FT>(P.vg_alpha, -u.n);
     u.Ksat = P.vg_Ksat;
+    u.inv_por = FT(1) / (u.nu - u.theta_r);
+    u.inv_S_s = FT(1) / u.S_s;
     {
         FT rho_b = (FT(1) - u.nu) * P.rho_p;
         FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -175,6 +178,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
         }
     P.consistent_bottom_sign = h.consistent_bottom_sign;
     P.status = c->d_status;
+    P.math_tab = c->d_math_tab;
     return P;
 }
 
@@ -386,6 +390,20 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
     CREATE_HIP(hipMalloc(&c->d_status, sizeof(uint32_t)));
     CREATE_HIP(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
     CREATE_HIP(hipMalloc(&c->d_dt, 8));
+    {
+        // tables of lh_fastmath.hpp, built in long double and rounded once
+        std::vector<double> tab(MATH_TAB_DOUBLES);
+        for (int i = 0; i < LOG_TAB_N; ++i) {
+            long double cc = 0.5L * (1.0L + (i + 0.5L) / LOG_TAB_N);
+            if (i == 0) cc = 0.5L;               // log2(1) == 0 exactly, and
+            if (i == LOG_TAB_N - 1) cc = 1.0L;   // nothing lost next to 1
+            tab[2 * i] = double(1.0L / cc);
+            tab[2 * i + 1] = double(log2l(cc));
+        }
+        for (int j = 0; j < EXP_TAB_N; ++j) tab[2 * LOG_TAB_N + j] = double(exp2l((long double)j / EXP_TAB_N));
+        CREATE_HIP(hipMalloc(&c->d_math_tab, tab.size() * sizeof(double)));
+        CREATE_HIP(hipMemcpy(c->d_math_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     c->zc_host.resize(cfg->nlev);
     if (cfg->dtype == LH_F64) {
         std::vector<double> z;
@@ -416,6 +434,7 @@ int lh_destroy(lh_ctx* c) {
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_dt) (void)hipFree(c->d_dt);
+    if (c->d_math_tab) (void)hipFree(c->d_math_tab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

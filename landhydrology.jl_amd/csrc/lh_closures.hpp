@@ -34,6 +34,8 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.inv_m = FT(1) / c.m;
     c.alpha_pnn = MathLibm<FT>::pow(alpha, -n); // once per column
     c.theta_lim = c.theta_r + Limits<FT>::eps();
+    c.inv_por = FT(1) / (c.nu - c.theta_r);
+    c.inv_S_s = FT(1) / c.S_s;
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
     FT rho_b = (FT(1) - c.nu) * P.rho_p;
     FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -53,28 +55,29 @@ __device__ __forceinline__ FT liquid_fraction(FT vl, FT nu_eff) {
 // pressure_head (:228-241), matric_potential (:195-199), the conductivity
 // factors (:76-126).  K uses the true porosity nu, psi uses nu_eff = nu - ti.
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
-__device__ __forceinline__ void water_closures(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
-                                               FT ti, FT T, FT& K, FT& psi) {
+__device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
+                                               const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
+                                               FT& psi) {
     const FT nu_eff = c.nu - ti;
-    const FT vls = (vl > c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps)
+    const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps), NaN kept
     const FT num = vls - c.theta_r;
-    const FT S = num / (c.nu - c.theta_r);
+    const FT S = num * c.inv_por; // / (nu - theta_r), reciprocal formed once per column
     // when ti == 0, nu_eff == nu bitwise and the two saturations coincide
-    const FT Se = (nu_eff == c.nu) ? S : num / (nu_eff - c.theta_r);
+    const FT Se = (nu_eff == c.nu) ? S : num * mm.rcp(nu_eff - c.theta_r);
 
     FT Kr;
     FT t_S = FT(0); // S^(1/m), reused by psi when Se == S
     if (S < FT(1)) {
-        t_S = M::pow(S, c.inv_m);
-        FT inner = FT(1) - M::pow(FT(1) - t_S, c.m);
-        Kr = M::sqrt(S) * (inner * inner); // (.)^FT(2)
+        t_S = mm.pow(S, c.inv_m);
+        FT inner = FT(1) - mm.pow(FT(1) - t_S, c.m);
+        Kr = mm.sqrt(S) * (inner * inner); // (.)^FT(2)
     } else {
         Kr = FT(1);
     }
     K = Kr * c.Ksat;
     if (FACTORS) {
         FT visc = FT(1), imp = FT(1);
-        if (P.viscosity_kind) visc = M::exp(P.gamma * (T - P.T_ref_visc));
+        if (P.viscosity_kind) visc = mm.exp(P.gamma * (T - P.T_ref_visc));
         if (P.impedance_kind) {
             FT tl = liquid_fraction(vl, nu_eff);
             FT f_i = ti / (tl + ti);
@@ -86,10 +89,10 @@ __device__ __forceinline__ void water_closures(const DevParams<FT>& P, const Col
     if (WANT_PSI) {
         if (Se <= FT(1)) {
             // S^(-1/m): share the power with K when the saturations coincide
-            FT r = (Se == S && S < FT(1)) ? M::rcp(t_S) : M::pow(Se, -c.inv_m);
-            psi = -M::pow((r - FT(1)) * c.alpha_pnn, c.inv_n);
+            FT r = (Se == S && S < FT(1)) ? mm.rcp(t_S) : mm.pow(Se, -c.inv_m);
+            psi = -mm.pow((r - FT(1)) * c.alpha_pnn, c.inv_n);
         } else {
-            psi = (vl - nu_eff) / c.S_s;
+            psi = (vl - nu_eff) * c.inv_S_s;
         }
     }
 }
@@ -99,21 +102,21 @@ __device__ __forceinline__ void water_closures(const DevParams<FT>& P, const Col
 // relative_saturation (:139-142), kersten_number (:152-174),
 // saturated_thermal_conductivity (:114-128), thermal_conductivity (:185-188).
 template <typename FT, typename M>
-__device__ __forceinline__ FT kappa_closure(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
-                                            FT ti) {
+__device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
+                                            const ColC<FT>& c, FT vl, FT ti) {
     const FT nu_eff = c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
     const FT tw = tl + ti;
     const FT S_r = tw / c.nu;
     FT K_e;
     if (ti < Limits<FT>::eps()) {
-        FT e = M::exp(-P.b * S_r);
-        FT a = M::pow_neg3(FT(1) + e);          // (1 + exp(-b S_r))^(-3)
+        FT e = mm.exp(-P.b * S_r);
+        FT a = mm.pow_neg3(FT(1) + e);          // (1 + exp(-b S_r))^(-3)
         FT h = (FT(1) - S_r) / FT(2);
         FT d = a - h * h * h;                   // ((1 - S_r)/2)^3
-        K_e = M::pow(S_r, P.kersten_exp_unfrozen) * M::pow(d, P.one_minus_om);
+        K_e = mm.pow(S_r, P.kersten_exp_unfrozen) * mm.pow(d, P.one_minus_om);
     } else {
-        K_e = M::pow(S_r, P.kersten_exp_frozen);
+        K_e = mm.pow(S_r, P.kersten_exp_frozen);
     }
     FT k_sat;
     if (tw < Limits<FT>::eps()) {
@@ -122,7 +125,7 @@ __device__ __forceinline__ FT kappa_closure(const DevParams<FT>& P, const ColC<F
         // kappa_unf^(tl/tw) * kappa_fr^0 with tl/tw == 1 exactly
         k_sat = P.kappa_sat_unfrozen;
     } else {
-        k_sat = M::pow(P.kappa_sat_unfrozen, tl / tw) * M::pow(P.kappa_sat_frozen, ti / tw);
+        k_sat = mm.pow(P.kappa_sat_unfrozen, tl / tw) * mm.pow(P.kappa_sat_frozen, ti / tw);
     }
     return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
 }
@@ -142,9 +145,10 @@ __device__ __forceinline__ FT temperature_closure(const DevParams<FT>& P, const 
 // to the face; K_c/psi_c are the values the interior stage already computed
 // (the reference recomputes them on a 2-element array: same numbers).
 template <typename FT, typename M, int MODEL, bool FACTORS>
-__device__ __forceinline__ void boundary_fluxes(const DevParams<FT>& P, const ColC<FT>& c,
-                                                int face, int64_t col, FT vl_c, FT ti_c, FT T_c,
-                                                FT K_c, FT psi_c, FT& f_e, FT& f_w) {
+__device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>& P,
+                                                const ColC<FT>& c, int face, int64_t col, FT vl_c,
+                                                FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
+                                                FT& f_w) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     const int ke = P.bc_kind[face][COMP_ENERGY];
@@ -165,7 +169,7 @@ __device__ __forceinline__ void boundary_fluxes(const DevParams<FT>& P, const Co
         if (ke == BC_FLUX) {
             f_e = ve;
         } else if (ke == BC_DIRICHLET) { // :416-444
-            FT kap_f = kappa_closure<FT, M>(P, c, vl_f, ti_c);
+            FT kap_f = kappa_closure<FT, M>(mm, P, c, vl_f, ti_c);
             f_e = sgn * (-kap_f * (T_f - T_c) / dzb);
         }
     }
@@ -176,7 +180,7 @@ __device__ __forceinline__ void boundary_fluxes(const DevParams<FT>& P, const Co
             f_w = -K_c;
         } else if (kh == BC_DIRICHLET) { // :371-401
             FT K_f, psi_f;
-            water_closures<FT, M, FACTORS>(P, c, vl_f, ti_c, T_f, K_f, psi_f);
+            water_closures<FT, M, FACTORS>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f);
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
                 f_w = K_f * (psi_f - psi_c - dzb) / dzb;
             else

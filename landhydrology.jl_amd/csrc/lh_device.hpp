@@ -22,6 +22,7 @@ struct ColC {
     FT alpha_pnn;                   // alpha^(-n)
     FT Ksat;
     FT k_dry;                       // SoilHeatParameterizations.jl:280-294
+    FT inv_por, inv_S_s;            // 1/(nu - theta_r), 1/S_s
 };
 
 // Everything a launch needs, already rounded to the working type FT the way the
@@ -62,6 +63,7 @@ struct DevParams {
     int32_t consistent_bottom_sign;
 
     uint32_t* status; // device word; bit 0 = non-finite tendency seen
+    const double* math_tab; // device copy of the log2/exp2 tables (lh_fastmath.hpp)
 };
 
 // one FieldVector on the device: up to four planes [nlev][stride]

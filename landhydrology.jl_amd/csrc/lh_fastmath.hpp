@@ -1,8 +1,20 @@
 // lh_fastmath.hpp -- math policies for the soil closures on gfx950.
 //
-//  MathLibm<FT>  ocml pow/exp/log: <= 1 ulp, the reference-faithful policy used
-//                for parity debugging and for once-per-column constants.
-//  MathFast<FT>  the production policy (see the second half of this file).
+//  MathLibm<FT>  ocml pow/exp: <= 1 ulp, the reference-faithful policy used for
+//                parity debugging (LH_MATH_LIBM) and once-per-column constants.
+//  MathFast<FT>  the production policy.
+//     double: pow(x, y) = exp2(y * log2 x) with LDS-resident tables --
+//        log2: x = m 2^e (v_frexp), 256 intervals on m in [0.5, 1) give
+//              (1/c, log2 c) from LDS, r = fma(m, 1/c, -1) with |r| < 2^-8 and a
+//              degree-6 polynomial; c = 0.5 and c = 1 at the two ends so
+//              log2(1) == 0 exactly and arguments next to 1 lose nothing;
+//        exp2: t = k/128 + r, 2^(j/128) from LDS, degree-5 polynomial, v_ldexp.
+//        ~37 VALU instructions per pow against several hundred for ocml's
+//        correctly-rounded pow: CDNA4 has no f64 transcendental unit, and at
+//        1e6 x 64 cells the f64 pows -- not HBM -- set the kernel's speed.
+//        Error: |rel| <= (2.5 |y log2 x| ln 2 + 2) 2^-53, i.e. the rounding of
+//        the exponent product; the parity tolerance model accounts for it.
+//     float: v_log_f32 / v_exp_f32 (hardware, ~1 ulp each).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,9 +28,25 @@ template <> struct Limits<float> {
     __host__ __device__ static constexpr float eps() { return 1.1920928955078125e-07f; } // eps(Float32)
 };
 
+// ---------------------------------------------------------------- tables
+constexpr int LOG_TAB_N = 256;  // entries of (1/c, log2 c)
+constexpr int EXP_TAB_N = 128;  // entries of 2^(j/128)
+constexpr int MATH_TAB_DOUBLES = 2 * LOG_TAB_N + EXP_TAB_N;
+
+// Shared-memory image of the tables: [0, 512) log pairs, [512, 640) exp2.
+struct MathTables {
+    const double* log_tab; // LDS, pairs
+    const double* exp_tab; // LDS
+};
+
+// ------------------------------------------------------------------ libm
 template <typename FT> struct MathLibm;
 
 template <> struct MathLibm<double> {
+    static constexpr bool uses_tables = false;
+    static constexpr bool is_production = false;
+    __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
+    __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
@@ -26,6 +54,10 @@ template <> struct MathLibm<double> {
     static __device__ __forceinline__ double pow_neg3(double x) { return ::pow(x, -3.0); }
 };
 template <> struct MathLibm<float> {
+    static constexpr bool uses_tables = false;
+    static constexpr bool is_production = false;
+    __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
+    __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
     static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
@@ -33,7 +65,103 @@ template <> struct MathLibm<float> {
     static __device__ __forceinline__ float pow_neg3(float x) { return ::powf(x, -3.0f); }
 };
 
-// Production policy: replaced below once the custom kernels are validated.
-template <typename FT> struct MathFast : MathLibm<FT> {};
+// ------------------------------------------------------------------ fast
+template <typename FT> struct MathFast;
+
+template <> struct MathFast<double> {
+    static constexpr bool uses_tables = true;
+    static constexpr bool is_production = true;
+    MathTables tb;
+    __device__ __forceinline__ explicit MathFast(const MathTables& t) : tb(t) {}
+
+    // log2 of a positive, finite, normal x
+    __device__ __forceinline__ double log2_core(double x) const {
+        const double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
+        const int e = __builtin_amdgcn_frexp_exp(x);     // x = m 2^e
+        const unsigned hi = (unsigned)__double2hiint(m);
+        const int i = (hi >> 12) & (LOG_TAB_N - 1);      // top 8 fraction bits
+        const double invc = tb.log_tab[2 * i];
+        const double l2c = tb.log_tab[2 * i + 1];
+        const double r = __builtin_fma(m, invc, -1.0);   // |r| < 2^-8
+        // log2(1 + r) = r (c1 + r (c2 + ... r c6)),  c_k = (-1)^(k+1) / (k ln 2)
+        double p = -0.24044917348149393;                 // c6 = -1/(6 ln2)
+        p = __builtin_fma(p, r, 0.28853900817779268);    // c5
+        p = __builtin_fma(p, r, -0.36067376022224085);   // c4
+        p = __builtin_fma(p, r, 0.48089834696298783);    // c3
+        p = __builtin_fma(p, r, -0.72134752044448170);   // c2
+        p = __builtin_fma(p, r, 1.4426950408889634);     // c1 = 1/ln2
+        return __builtin_fma(r, p, (double)e + l2c);
+    }
+
+    // 2^t for |t| <= 1100 (larger magnitudes saturate to 0 / inf through v_ldexp)
+    __device__ __forceinline__ double exp2_core(double t) const {
+        t = __builtin_fmin(__builtin_fmax(t, -1100.0), 1100.0);
+        const double kd = __builtin_rint(t * (double)EXP_TAB_N);
+        const double r = __builtin_fma(kd, -1.0 / EXP_TAB_N, t); // exact, |r| <= 2^-8
+        const int k = (int)kd;
+        const double tj = tb.exp_tab[k & (EXP_TAB_N - 1)];
+        const int e = k >> 7;
+        // 2^r - 1 = r (q1 + r (q2 + ... r q5)),  q_k = ln2^k / k!
+        double p = 1.3333558146428443e-3;                     // q5
+        p = __builtin_fma(p, r, 9.6181291076284772e-3);       // q4
+        p = __builtin_fma(p, r, 5.5504108664821580e-2);       // q3
+        p = __builtin_fma(p, r, 2.4022650695910071e-1);       // q2
+        p = __builtin_fma(p, r, 6.9314718055994531e-1);       // q1 = ln2
+        const double res = __builtin_fma(tj, r * p, tj);
+        return __builtin_amdgcn_ldexp(res, e);
+    }
+
+    // x^y with libm's results for the special bases the closures can produce:
+    // x == 0 (0 or inf by the sign of y), x < 0 or NaN (NaN; the reference raises
+    // DomainError there), x == inf.
+    __device__ __forceinline__ double pow(double x, double y) const {
+        const double xs = (x > 0.0 && x < __builtin_inf()) ? x : 1.0;
+        double res = exp2_core(y * log2_core(xs));
+        if (x == 0.0) res = (y > 0.0) ? 0.0 : __builtin_inf();
+        if (x == __builtin_inf()) res = (y > 0.0) ? __builtin_inf() : 0.0;
+        if (!(x >= 0.0) || y != y) res = __builtin_nan("");
+        return res;
+    }
+    __device__ __forceinline__ double exp(double x) const {
+        double res = exp2_core(x * 1.4426950408889634);
+        return (x != x) ? x : res;
+    }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    // 1/x by v_rcp_f64 and two Newton steps: < 1 ulp for normal x, no
+    // div_scale/div_fixup (the closures only take reciprocals of normal values)
+    static __device__ __forceinline__ double rcp(double x) {
+        double y = __builtin_amdgcn_rcp(x);
+        double e = __builtin_fma(-x, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-x, y, 1.0);
+        return __builtin_fma(y, e, y);
+    }
+    static __device__ __forceinline__ double pow_neg3(double x) {
+        const double y = rcp(x);
+        return y * y * y;
+    }
+};
+
+template <> struct MathFast<float> {
+    static constexpr bool uses_tables = false;
+    static constexpr bool is_production = true;
+    __device__ __forceinline__ explicit MathFast(const MathTables&) {}
+    // v_log_f32 / v_exp_f32: log2(0) = -inf, log2(<0) = NaN, so the special bases
+    // fall out of the hardware semantics (x = 0: y * -inf = -/+inf -> 0 / inf).
+    static __device__ __forceinline__ float pow(float x, float y) {
+        float res = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+        if (x == 1.0f || y == 0.0f) res = 1.0f; // keep 1^y and x^0 exact
+        return res;
+    }
+    static __device__ __forceinline__ float exp(float x) {
+        return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+    }
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+    static __device__ __forceinline__ float pow_neg3(float x) {
+        const float y = 1.0f / x;
+        return y * y * y;
+    }
+};
 
 } // namespace lh

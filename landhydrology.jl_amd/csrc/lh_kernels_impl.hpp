@@ -8,6 +8,7 @@
 // cell and the previous face flux in registers: each face flux is computed once
 // and differenced, which keeps the discrete mass/energy conservation the
 // reference's equilibrium tests rely on (coupled.jl:117, richards_equation.jl:94).
+#pragma once
 #include "lh_closures.hpp"
 #include "lh_launch.hpp"
 
@@ -40,6 +41,20 @@ __device__ __forceinline__ void vstore(FT* p, const FT (&in)[N]) {
     *reinterpret_cast<V*>(p) = v;
 }
 
+// Stage the log2/exp2 tables of MathFast<double> in LDS (5 KiB per workgroup);
+// every thread of the block must call this before any thread leaves.
+template <typename M>
+__device__ __forceinline__ MathTables stage_math_tables(const double* gtab, double* lds) {
+    MathTables t;
+    t.log_tab = lds;
+    t.exp_tab = lds + 2 * LOG_TAB_N;
+    if (M::uses_tables) {
+        for (int i = threadIdx.x; i < MATH_TAB_DOUBLES; i += blockDim.x) lds[i] = gtab[i];
+        __syncthreads();
+    }
+    return t;
+}
+
 template <typename FT>
 __device__ __forceinline__ bool finite(FT x) {
     return x - x == FT(0);
@@ -64,6 +79,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
            const Planes<FT> OUT, const FT dt) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 1];
+    const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     const int64_t col0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * CPL;
     if (col0 >= P.ncols) return;
     const int64_t stride = P.stride;
@@ -132,9 +149,9 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     if (MODE == 1)
                         r[j] = u[j] + dt * k[j];
                     else if (MODE == 2)
-                        r[j] = (FT(3) * b[j] + u[j] + dt * k[j]) / FT(4);
+                        r[j] = (FT(3) * b[j] + u[j] + dt * k[j]) * FT(0.25);
                     else
-                        r[j] = (b[j] + FT(2) * u[j] + FT(2) * dt * k[j]) / FT(3);
+                        r[j] = (b[j] + FT(2) * u[j] + FT(2) * dt * k[j]) * FT(1.0 / 3.0);
                 }
                 vstore<FT, CPL>(OUT.v[var] + o, r);
             };
@@ -171,10 +188,10 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             if (HEAT) {
                 FT rcs;
                 T[j] = temperature_closure<FT>(P, c[j], vl[j], ti[j], re[j], rcs);
-                kap[j] = kappa_closure<FT, M>(P, c[j], vl[j], ti[j]);
+                kap[j] = kappa_closure<FT, M>(mm, P, c[j], vl[j], ti[j]);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS>(P, c[j], vl[j], ti[j], T[j], K[j], psi[j]);
+                water_closures<FT, M, FACTORS>(mm, P, c[j], vl[j], ti[j], T[j], K[j], psi[j]);
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
@@ -182,7 +199,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         if (i == 0) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j)
-                boundary_fluxes<FT, M, MODEL, FACTORS>(P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
+                boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
                                                        T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j]);
         } else {
             FT Fw[CPL], Fe[CPL];
@@ -224,7 +241,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         FT Fw[CPL], Fe[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
-            boundary_fluxes<FT, M, MODEL, FACTORS>(P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
+            boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
                                                    K_p[j], psi_p[j], Fe[j], Fw[j]);
         emit(n - 1, Fw, Fe, vl_p, ti_p, re_p);
     }
@@ -238,6 +255,8 @@ __global__ void __launch_bounds__(256)
 diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> OUT) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 1];
+    const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     const int64_t col = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (col >= P.ncols) return;
     const FT* p_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + col;
@@ -251,9 +270,9 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
         if (HEAT) {
             FT rcs;
             T = temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
-            kap = kappa_closure<FT, M>(P, c, vl, ti);
+            kap = kappa_closure<FT, M>(mm, P, c, vl, ti);
         }
-        if (WATER) water_closures<FT, M, FACTORS>(P, c, vl, ti, T, K, psi);
+        if (WATER) water_closures<FT, M, FACTORS>(mm, P, c, vl, ti, T, K, psi);
         OUT.v[0][o + col] = K;
         OUT.v[1][o + col] = psi;
         OUT.v[2][o + col] = kap;
@@ -276,6 +295,8 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     using U = typename Bits<FT>::type;
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 1];
+    const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     const int64_t col = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     FT best = FT(INFINITY);
     if (col < P.ncols) {
@@ -289,11 +310,11 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
             FT D = FT(0);
             if (WATER) {
                 FT K, psi;
-                water_closures<FT, M, true>(P, c, vl, ti, FT(288), K, psi);
+                water_closures<FT, M, true>(mm, P, c, vl, ti, FT(288), K, psi);
                 const FT nu_eff = c.nu - ti;
-                const FT vls = (vl > c.theta_lim) ? vl : c.theta_lim;
+                const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
                 const FT Se = (vls - c.theta_r) / (nu_eff - c.theta_r);
-                const FT u = M::pow(Se, -c.inv_m) - FT(1);
+                const FT u = mm.pow(Se, -c.inv_m) - FT(1);
                 FT dpsi;
                 if (Se <= FT(1) && u > FT(0))
                     dpsi = fabs(psi) * (u + FT(1)) / (c.n * c.m * u * Se * (nu_eff - c.theta_r));
@@ -304,7 +325,7 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
             if (HEAT) {
                 FT rcs;
                 (void)temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
-                FT DT = kappa_closure<FT, M>(P, c, vl, ti) / rcs;
+                FT DT = kappa_closure<FT, M>(mm, P, c, vl, ti) / rcs;
                 if (DT > D) D = DT;
             }
             if (D > FT(0)) {
@@ -396,6 +417,10 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
                             hipStream_t s) {
     const int64_t lanes = (P.ncols + CPL - 1) / CPL;
     dim3 g = grid_for(lanes, 256), b(256);
+    if (!M::is_production) { // MathLibm: tendency only
+        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CPL, M, 0>), g, b, 0, s, P, in, aux, base, out, dt);
+        return;
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CPL, M, 0>), g, b, 0, s, P, in, aux, base, out, dt); break;
         case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CPL, M, 1>), g, b, 0, s, P, in, aux, base, out, dt); break;
@@ -428,7 +453,9 @@ void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& 
         case MODEL_HEAT: launch_rhs_model<FT, MODEL_HEAT, MATH>(P, in, aux, base, out, dt, mode, factors, percol, s); break;         \
         default: launch_rhs_model<FT, MODEL_COUPLED, MATH>(P, in, aux, base, out, dt, mode, factors, percol, s); break;              \
     }
-    if (math == MATH_LIBM) {
+    // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
+    // the fused SSPRK33 stages always run the production math.
+    if (math == MATH_LIBM && mode == 0) {
         LH_DISPATCH_MODEL(MathLibm<FT>)
     } else {
         LH_DISPATCH_MODEL(MathFast<FT>)
@@ -503,8 +530,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL((convert_kernel<FT>), grid_for(n, 256), dim3(256), 0, s, dst, src, n);
 }
 
-// explicit instantiations for the two working types
-#define LH_INST(FT)                                                                                   \
+// explicit instantiation for one working type per translation unit
+#define LH_INSTANTIATE(FT)                                                                            \
     template void launch_rhs<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,          \
                                  const Planes<FT>&, const Planes<FT>&, FT, int, bool, bool, int,      \
                                  hipStream_t);                                                        \
@@ -516,8 +543,5 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
                                           hipStream_t);                                               \
     template void launch_fill<FT>(FT*, int64_t, FT, hipStream_t);                                     \
     template void launch_convert<FT>(FT*, const double*, int64_t, hipStream_t);
-LH_INST(float)
-LH_INST(double)
-#undef LH_INST
 
 } // namespace lh

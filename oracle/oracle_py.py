@@ -232,7 +232,10 @@ def _strides(a: np.ndarray):
     2-D strided view; returns element strides (lev, col)."""
     assert a.ndim == 2
     it = a.itemsize
-    return a.strides[1] // it, a.strides[0] // it
+    # numpy reports arbitrary strides for length-1 axes: normalise them
+    ls = a.strides[1] // it if a.shape[1] > 1 else 1
+    cs = a.strides[0] // it if a.shape[0] > 1 else max(1, a.shape[1] * ls)
+    return ls, cs
 
 
 def grid(zmin, zmax, n, dtype=np.float64):

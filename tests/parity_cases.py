@@ -280,20 +280,27 @@ class GpuModel:
             self.upload(h, var, a)
         return h
 
+    @staticmethod
+    def _strides(a):
+        """Element strides (lev, col); numpy reports arbitrary strides for
+        length-1 axes, so normalise those."""
+        it = a.itemsize
+        ls = a.strides[1] // it if a.shape[1] > 1 else 1
+        cs = a.strides[0] // it if a.shape[0] > 1 else max(1, a.shape[1] * max(ls, 1))
+        return ls, cs
+
     def upload(self, h, var, a):
         a = np.asarray(a)
         assert a.dtype == self.case.dtype and a.ndim == 2
-        it = a.itemsize
-        self.F.check(self.L.lh_upload(self.ctx, h, var, a.ctypes.data, a.strides[1] // it,
-                                      a.strides[0] // it), self.ctx)
+        ls, cs = self._strides(a)
+        self.F.check(self.L.lh_upload(self.ctx, h, var, a.ctypes.data, ls, cs), self.ctx)
 
     def download(self, h, var, out=None):
         om = self.case.om
         if out is None:
             out = np.empty((self.case.ncols, om.nlev), dtype=self.case.dtype)
-        it = out.itemsize
-        self.F.check(self.L.lh_download(self.ctx, h, var, out.ctypes.data, out.strides[1] // it,
-                                        out.strides[0] // it), self.ctx)
+        ls, cs = self._strides(out)
+        self.F.check(self.L.lh_download(self.ctx, h, var, out.ctypes.data, ls, cs), self.ctx)
         return out
 
     def prognostic_and_aux(self):
@@ -301,7 +308,6 @@ class GpuModel:
         F, c = self.F, self.case
         m = c.om.model
         if m == F.LH_MODEL_HEAT:
-            Y = self.state(0, **{str(F.LH_VAR_RHOE_INT): c.rhoe}) if False else None
             Y = self.state(0)
             self.upload(Y, F.LH_VAR_RHOE_INT, c.rhoe)
             Ya = self.state(0b0011)

@@ -3,8 +3,11 @@ CPU oracle on the same seeded inputs (tests/parity_cases.py).
 
 Tolerance: `tendency_tolerance` propagates Cw*eps(FT) through the cancelling
 sub-expressions of the closures and the flux differences (see parity_cases.py).
-Cw = 4 for both working types: i.e. the two implementations may differ by a few
-units of rounding per operation, nothing more.  d(theta_i) must be exactly 0.
+Cw = 4 (Float64, and Float32 with the libm policy): the two implementations may
+differ by a few units of rounding per operation, nothing more.  Cw = 16 for the
+Float32 production policy, whose pow is exp2(y log2 x) on the hardware
+v_log_f32 / v_exp_f32 units (about 1 ulp each, six of them in the K chain).
+d(theta_i) must be exactly 0.
 """
 import numpy as np
 import pytest
@@ -14,6 +17,11 @@ import parity_cases as pc
 pytestmark = pytest.mark.gpu
 
 CW = 4.0
+
+
+def cw(case, math="fast"):
+    return 16.0 if (case.dtype == np.float32 and math == "fast") else CW
+
 CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128",
          "c3_coupled_f32", "c3_coupled_f64", "c5_percol_f64", "heat_dirichlet_f64",
          "heat_dirichlet_f32", "mixed_factors_f64", "mixed_factors_f32", "richards_viscosity_f64",
@@ -28,7 +36,7 @@ def test_rhs_matches_oracle(name, math):
     mode = F.LH_MATH_FAST if math == "fast" else F.LH_MATH_LIBM
     got = pc.run_gpu_rhs(case, mode)
     want = pc.run_oracle_rhs(case)
-    pc.assert_tendencies_close(case, got, want, CW, label=f"[{math}]")
+    pc.assert_tendencies_close(case, got, want, cw(case, math), label=f"[{math}]")
 
 
 @pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_factors_f64",
@@ -38,7 +46,7 @@ def test_closures_match_oracle(name):
     case = pc.make_case(name)
     got = pc.run_gpu_diagnostics(case)
     want = pc.O.diagnostics(case.om, case.vl, case.ti, case.rhoe, case.T_aux)
-    tol = pc.closure_tolerances(case, want, CW)
+    tol = pc.closure_tolerances(case, want, cw(case))
     for k in ("K", "psi", "T", "kappa"):
         if case.om.model == pc.O.MODEL_RICHARDS and k in ("T", "kappa"):
             continue
@@ -53,7 +61,7 @@ def test_ragged_and_tiny_batches():
             case = pc.make_case(name, ncols=ncols)
             got = pc.run_gpu_rhs(case)
             want = pc.run_oracle_rhs(case)
-            pc.assert_tendencies_close(case, got, want, CW, label=f"[ncols={ncols}]")
+            pc.assert_tendencies_close(case, got, want, cw(case), label=f"[ncols={ncols}]")
 
 
 def test_upload_download_roundtrip_layouts():
