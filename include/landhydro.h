@@ -166,6 +166,11 @@ int lh_set_bottom_sign_consistent(lh_ctx*, int32_t flag);
 /* LH_MATH_* (default LH_MATH_FAST; the environment variable LH_MATH=libm
  * selects LH_MATH_LIBM at lh_create) */
 int lh_set_math_mode(lh_ctx*, int32_t mode);
+/* launch-shape override for measurements, e.g. "block=128" (threads per
+ * workgroup: 64, 128, 192 or 256); "" restores the defaults.  The environment
+ * variable LH_TUNE is read the same way at lh_create.  Results do not depend
+ * on it. */
+int lh_set_tuning(lh_ctx*, const char* spec);
 
 /* ---- states ---------------------------------------------------------------- */
 

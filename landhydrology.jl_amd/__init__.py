@@ -6,7 +6,7 @@ The directory name contains a dot, so it is loaded through
 `landhydrology_jl_amd`.  Compute lives in lib/liblandhydro_hip.so (HIP, gfx950);
 this package is the host-side mirror of the reference's Julia interface.
 """
-from . import _ffi
+from . import _ffi, partition
 from ._ffi import LandHydroError, ModelError
 from .soil import (Column, Dirichlet, EarthParameterSet, FieldVector, Float32, Float64,
                    FreeDrainage, IceImpedance, NoBC, NoEffect, PrescribedAtmosForcing,

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lh_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _DP]),
     "lh_set_bottom_sign_consistent": (C.c_int, [_P, C.c_int32]),
     "lh_set_math_mode": (C.c_int, [_P, C.c_int32]),
+    "lh_set_tuning": (C.c_int, [_P, C.c_char_p]),
     "lh_state_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     "lh_state_destroy": (C.c_int, [_P, _P]),
     "lh_upload": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, C.c_int64]),

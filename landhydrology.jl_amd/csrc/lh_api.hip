@@ -57,6 +57,7 @@ struct lh_ctx {
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int math = MATH_FAST;
+    Tune tune;
     std::vector<double> zc_host;
     std::string err;
     std::vector<lh_state*> states;
@@ -163,6 +164,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.Ksat = P.vg_Ksat;
     u.inv_por = FT(1) / (u.nu - u.theta_r);
     u.inv_S_s = FT(1) / u.S_s;
+    u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
     {
         FT rho_b = (FT(1) - u.nu) * P.rho_p;
         FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -180,6 +182,17 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.status = c->d_status;
     P.math_tab = c->d_math_tab;
     return P;
+}
+
+// "block=128,pf=2,nt=1,cpl=2": launch-shape overrides (lh_launch.hpp, Tune)
+void parse_tune(Tune& tu, const char* t) {
+    tu = Tune();
+    int v;
+    const char* q;
+    if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
+    if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
+    if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
+    if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;
 }
 
 bool any_percol(const lh_ctx* c) {
@@ -259,7 +272,7 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
             for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
     launch_rhs<FT>(P, planes_of<FT>(in), planes_of<FT>(aux), planes_of<FT>(base), planes_of<FT>(out),
-                   FT(dt), mode, factors, any_percol(c), c->math, c->stream);
+                   FT(dt), mode, factors, any_percol(c), c->math, c->tune, c->stream);
     LH_HIP(c, hipGetLastError());
     return LH_OK;
 }
@@ -366,6 +379,7 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
     c->hp.soil = lh_soil_params{0.43, 1e-3, 0.0, 0.0, 0.41, 2700.0, 3.97, 2700.0, 1.72, 3.13, 0.24, 18.1, 0.053};
     if (const char* m = getenv("LH_MATH"))
         if (!strcmp(m, "libm")) c->math = MATH_LIBM;
+    if (const char* t = getenv("LH_TUNE")) parse_tune(c->tune, t);
 
 #define CREATE_HIP(call)                                                                           \
     do {                                                                                           \
@@ -495,6 +509,12 @@ int lh_set_bc(lh_ctx* c, int32_t face, int32_t comp, int32_t kind, double value,
 int lh_set_bottom_sign_consistent(lh_ctx* c, int32_t flag) {
     if (!c) return LH_EINVAL;
     c->hp.consistent_bottom_sign = flag ? 1 : 0;
+    return LH_OK;
+}
+
+int lh_set_tuning(lh_ctx* c, const char* spec) {
+    if (!c || !spec) return LH_EINVAL;
+    parse_tune(c->tune, spec);
     return LH_OK;
 }
 

@@ -36,6 +36,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.theta_lim = c.theta_r + Limits<FT>::eps();
     c.inv_por = FT(1) / (c.nu - c.theta_r);
     c.inv_S_s = FT(1) / c.S_s;
+    c.log2_alpha = MathLibm<FT>::log2(alpha);
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
     FT rho_b = (FT(1) - c.nu) * P.rho_p;
     FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -55,7 +56,7 @@ __device__ __forceinline__ FT liquid_fraction(FT vl, FT nu_eff) {
 // pressure_head (:228-241), matric_potential (:195-199), the conductivity
 // factors (:76-126).  K uses the true porosity nu, psi uses nu_eff = nu - ti.
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
-__device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
+__device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                FT& psi) {
     const FT nu_eff = c.nu - ti;
@@ -95,6 +96,71 @@ __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>&
             psi = (vl - nu_eff) * c.inv_S_s;
         }
     }
+}
+
+// The same closures in the log2 domain -- the production form.
+//   L = log2 S,  t = S^(1/m) = 2^(L/m),  w = 1 - t,  Lw = log2 w,
+//   K_r = sqrt(S) (1 - 2^(m Lw))^2,
+//   S^(-1/m) - 1 = w / t  =>  psi = -2^((Lw - L/m)/n - log2 alpha)
+// i.e. two logarithms and three exponentials per cell instead of four pows and
+// a reciprocal, and no second cancellation in S^(-1/m) - 1.  With ice (Se != S)
+// psi takes its own log2(Se), 2^(.), log2(1 - .).
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
+__device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
+                                                   const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
+                                                   FT& psi) {
+    const FT nu_eff = c.nu - ti;
+    const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps), NaN kept
+    const FT num = vls - c.theta_r;
+    const FT S = num * c.inv_por;
+    const bool same = (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
+    const FT Se = same ? S : num * mm.rcp(nu_eff - c.theta_r);
+
+    FT Kr = FT(1), a = FT(0), Lw = FT(0);
+    if (S < FT(1)) {
+        const FT L = mm.log2(S);
+        a = L * c.inv_m;               // log2 S^(1/m)
+        const FT w = FT(1) - mm.exp2(a);
+        Lw = mm.log2(w);
+        const FT inner = FT(1) - mm.exp2(c.m * Lw);
+        Kr = mm.sqrt(S) * (inner * inner);
+    }
+    K = Kr * c.Ksat;
+    if (FACTORS) {
+        FT visc = FT(1), imp = FT(1);
+        if (P.viscosity_kind) visc = mm.exp(P.gamma * (T - P.T_ref_visc));
+        if (P.impedance_kind) {
+            FT tl = liquid_fraction(vl, nu_eff);
+            FT f_i = ti / (tl + ti);
+            imp = FT(MathLibm<double>::pow(10.0, double(-P.Omega * f_i)));
+        }
+        K = K * visc * imp;
+    }
+    if (WANT_PSI) {
+        if (Se < FT(1)) {
+            FT ae = a, Lwe = Lw;
+            if (!(same && S < FT(1))) {
+                const FT Le = mm.log2(Se);
+                ae = Le * c.inv_m;
+                Lwe = mm.log2(FT(1) - mm.exp2(ae));
+            }
+            psi = -mm.exp2((Lwe - ae) * c.inv_n - c.log2_alpha);
+        } else if (Se == FT(1)) {
+            psi = -FT(0); // -((1 - 1) alpha^-n)^(1/n)
+        } else {
+            psi = (vl - nu_eff) * c.inv_S_s;
+        }
+    }
+    // a non-positive saturation (nu <= theta_r) is a DomainError in the reference
+    if (!(S > FT(0)) && !(S != S)) K = psi = FT(NAN);
+}
+
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
+__device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
+                                               const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
+                                               FT& psi) {
+    if (M::is_production) water_closures_log<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
+    else water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
 }
 
 // T, kappa (and rho_c_s) of one cell: right_hand_side.jl:291-305 with

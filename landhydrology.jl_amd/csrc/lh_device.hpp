@@ -23,6 +23,7 @@ struct ColC {
     FT Ksat;
     FT k_dry;                       // SoilHeatParameterizations.jl:280-294
     FT inv_por, inv_S_s;            // 1/(nu - theta_r), 1/S_s
+    FT log2_alpha;                  // log2(alpha), for the log-domain psi
 };
 
 // Everything a launch needs, already rounded to the working type FT the way the

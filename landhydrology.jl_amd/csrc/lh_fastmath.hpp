@@ -48,6 +48,8 @@ template <> struct MathLibm<double> {
     __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
     __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -59,6 +61,8 @@ template <> struct MathLibm<float> {
     __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
     __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
+    static __device__ __forceinline__ float log2(float x) { return ::log2f(x); }
+    static __device__ __forceinline__ float exp2(float x) { return ::exp2f(x); }
     static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
@@ -93,9 +97,9 @@ template <> struct MathFast<double> {
         return __builtin_fma(r, p, (double)e + l2c);
     }
 
-    // 2^t for |t| <= 1100 (larger magnitudes saturate to 0 / inf through v_ldexp)
+    // 2^t for finite t (huge |t| saturates to 0 / inf: v_cvt_i32 saturates and
+    // v_ldexp does the rest); NaN in, NaN out
     __device__ __forceinline__ double exp2_core(double t) const {
-        t = __builtin_fmin(__builtin_fmax(t, -1100.0), 1100.0);
         const double kd = __builtin_rint(t * (double)EXP_TAB_N);
         const double r = __builtin_fma(kd, -1.0 / EXP_TAB_N, t); // exact, |r| <= 2^-8
         const int k = (int)kd;
@@ -114,9 +118,13 @@ template <> struct MathFast<double> {
     // x^y with libm's results for the special bases the closures can produce:
     // x == 0 (0 or inf by the sign of y), x < 0 or NaN (NaN; the reference raises
     // DomainError there), x == inf.
+    __device__ __forceinline__ double log2(double x) const { return log2_core(x); }
+    __device__ __forceinline__ double exp2(double t) const { return exp2_core(t); }
     __device__ __forceinline__ double pow(double x, double y) const {
         const double xs = (x > 0.0 && x < __builtin_inf()) ? x : 1.0;
-        double res = exp2_core(y * log2_core(xs));
+        double t = y * log2_core(xs);
+        t = __builtin_fmin(__builtin_fmax(t, -1100.0), 1100.0);
+        double res = exp2_core(t);
         if (x == 0.0) res = (y > 0.0) ? 0.0 : __builtin_inf();
         if (x == __builtin_inf()) res = (y > 0.0) ? __builtin_inf() : 0.0;
         if (!(x >= 0.0) || y != y) res = __builtin_nan("");
@@ -126,7 +134,19 @@ template <> struct MathFast<double> {
         double res = exp2_core(x * 1.4426950408889634);
         return (x != x) ? x : res;
     }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    // sqrt of a positive normal x: v_rsq_f64 seed, one coupled Newton step and a
+    // final residual correction (no range scaling: the closures take sqrt(S),
+    // S in [eps, 1))
+    static __device__ __forceinline__ double sqrt(double x) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y;
+        double h = 0.5 * y;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        const double d = __builtin_fma(-g, g, x);
+        return __builtin_fma(d, h, g);
+    }
     // 1/x by v_rcp_f64 and two Newton steps: < 1 ulp for normal x, no
     // div_scale/div_fixup (the closures only take reciprocals of normal values)
     static __device__ __forceinline__ double rcp(double x) {
@@ -153,6 +173,8 @@ template <> struct MathFast<float> {
         if (x == 1.0f || y == 0.0f) res = 1.0f; // keep 1^y and x^0 exact
         return res;
     }
+    static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
+    static __device__ __forceinline__ float exp2(float t) { return __builtin_amdgcn_exp2f(t); }
     static __device__ __forceinline__ float exp(float x) {
         return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
     }

@@ -6,16 +6,23 @@ namespace lh {
 
 enum { MATH_FAST = 0, MATH_LIBM = 1 };
 
-// columns per lane: 16 B per lane and level for both working types
-template <typename FT> struct LH_CPL;
-template <> struct LH_CPL<double> { static constexpr int value = 1; };
-template <> struct LH_CPL<float> { static constexpr int value = 2; };
+template <int CPL_, int PF_, bool NT_> struct KCfg;
+// production launch shape per working type (chosen by measurement)
+template <typename FT> struct DefaultCfg;
+template <> struct DefaultCfg<double> { using type = KCfg<1, 1, false>; };
+template <> struct DefaultCfg<float> { using type = KCfg<2, 1, false>; };
+
+// run-time launch overrides (LH_TUNE environment variable; tuning builds only
+// honour cpl/pf/nt, every build honours block)
+struct Tune {
+    int block = 0, cpl = 0, pf = 0, nt = -1;
+};
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, int mode, bool factors,
-                bool percol, int math, hipStream_t s);
+                bool percol, int math, const Tune& tune, hipStream_t s);
 template <typename FT>
 void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                  const Planes<FT>& out, bool percol, int math, hipStream_t s);

@@ -1,0 +1,36 @@
+"""Block partition of an ensemble of independent columns over ranks (one process
+per GPU), and the one collective of the path: the global stable-dt minimum.
+
+The reference has one column and no parallelism; columns are
+fully independent, so rank r of W owns the contiguous block
+[r*N/W, (r+1)*N/W) with no halo and no data-path collective.  Only the
+build-defined adaptive step needs communication: a single `min` all-reduce of
+one FT value per step (RCCL over xGMI on GPUs: backend "nccl"; gloo on CPU).
+With a user-supplied fixed dt -- what the reference does -- nothing is exchanged
+and every rank's results equal the single-process run bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def block_range(ncols_global: int, rank: int, world: int) -> Tuple[int, int]:
+    """Half-open column range [lo, hi) owned by `rank`; the first N % W ranks get
+    one extra column."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside [0, {world})")
+    if ncols_global < world:
+        raise ValueError("fewer columns than ranks")
+    q, r = divmod(ncols_global, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def global_min_dt(local_dt_tensor, group=None):
+    """All-reduce (min) of the local stable dt, in place, on whatever device the
+    tensor lives on: a device tensor written by `lh_stable_dt_device` stays on the
+    GPU (no host round trip).  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_dt_tensor, op=dist.ReduceOp.MIN, group=group)
+    return local_dt_tensor
