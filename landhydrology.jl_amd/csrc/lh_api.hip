@@ -697,8 +697,7 @@ int lh_stable_dt_device(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double
     if (model_heat(c->cfg.model) && !c->hp.earth_set)
         return fail(c, LH_EINVAL, "earth parameters (lh_set_earth_params) are required by the energy model");
     if ((rc = check_state(c, Y, prognostic_mask(c->cfg.model), "Y"))) return rc;
-    uint32_t am = c->cfg.model == LH_MODEL_HEAT ? aux_mask(c) : 0;
-    if ((rc = check_state(c, Ya, am, "Ya"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
     if (c->cfg.dtype == LH_F64) {
         DevParams<double> P = make_params<double>(c);

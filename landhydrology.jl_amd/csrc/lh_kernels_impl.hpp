@@ -327,34 +327,66 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
         const FT* p_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : IN.v[1]) + col;
         const ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
         const FT cdz2 = courant * P.dz * P.dz;
-        for (int i = 0; i < P.nlev; ++i) {
+        const int n = P.nlev;
+        FT K_p = FT(0), dpsi_p = FT(0), kap_p = FT(0), rcs_p = FT(1);
+        for (int i = 0; i < n; ++i) {
             const int64_t o = int64_t(i) * P.stride;
             FT vl = p_vl[o], ti = p_ti[o];
-            FT D = FT(0);
+            FT K = FT(0), dpsi = FT(0), kap = FT(0), rcs = FT(1);
+            FT Tc = FT(288);
+            if (MODEL == MODEL_RICHARDS && P.viscosity_kind) Tc = AUX.v[3][o + col];
+            if (HEAT) Tc = temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
             if (WATER) {
-                FT K, psi;
-                water_closures<FT, M, true>(mm, P, c, vl, ti, FT(288), K, psi);
+                FT psi;
+                water_closures<FT, M, true>(mm, P, c, vl, ti, Tc, K, psi);
                 const FT nu_eff = c.nu - ti;
                 const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
                 const FT Se = (vls - c.theta_r) / (nu_eff - c.theta_r);
                 const FT u = mm.pow(Se, -c.inv_m) - FT(1);
-                FT dpsi;
                 if (Se <= FT(1) && u > FT(0))
                     dpsi = fabs(psi) * (u + FT(1)) / (c.n * c.m * u * Se * (nu_eff - c.theta_r));
                 else
                     dpsi = FT(1) / c.S_s;
-                D = K * dpsi;
             }
-            if (HEAT) {
-                FT rcs;
-                (void)temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
-                FT DT = kappa_closure<FT, M>(mm, P, c, vl, ti) / rcs;
+            if (HEAT) kap = kappa_closure<FT, M>(mm, P, c, vl, ti);
+            FT D = FT(0);
+            if (i == 0 || i == n - 1) { // boundary cells: their own coefficients
+                D = K * dpsi;
+                if (HEAT && kap / rcs > D) D = kap / rcs;
+                // Dirichlet faces sit half a cell away and use the face state's coefficients
+                for (int face = 0; face < 2; ++face) {
+                    if ((face == FACE_BOTTOM) != (i == 0) && n > 1) continue;
+                    const int kh = P.bc_kind[face][COMP_HYDROLOGY], ke = P.bc_kind[face][COMP_ENERGY];
+                    FT vh = P.bc_value[face][COMP_HYDROLOGY];
+                    if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
+                    const FT vl_f = (WATER && kh == BC_DIRICHLET) ? vh : vl;
+                    if (WATER && kh == BC_DIRICHLET) {
+                        FT K_f, psi_f;
+                        water_closures<FT, M, true, false>(mm, P, c, vl_f, ti, FT(288), K_f, psi_f);
+                        FT Db = FT(2) * (K_f > K ? K_f : K) * dpsi;
+                        if (Db > D) D = Db;
+                    }
+                    if (HEAT && ke == BC_DIRICHLET) {
+                        FT kf = kappa_closure<FT, M>(mm, P, c, vl_f, ti);
+                        FT Db = FT(2) * (kf > kap ? kf : kap) / rcs;
+                        if (Db > D) D = Db;
+                    }
+                }
+            }
+            if (i > 0) { // interior face: arithmetic-mean coefficients as in the stencil
+                FT Dw = (K_p + K) * FT(0.5) * (dpsi_p > dpsi ? dpsi_p : dpsi);
+                FT DT = HEAT ? (kap_p + kap) * FT(0.5) / (rcs_p < rcs ? rcs_p : rcs) : FT(0);
+                if (Dw > D) D = Dw;
                 if (DT > D) D = DT;
             }
             if (D > FT(0)) {
                 FT dtc = cdz2 / D;
                 if (dtc < best) best = dtc;
             }
+            K_p = K;
+            dpsi_p = dpsi;
+            kap_p = kap;
+            rcs_p = rcs;
         }
     }
     // wave64 reduction, then one atomic per wave

@@ -194,13 +194,14 @@ int lho_ssprk33_f32(const lho_model*, const lho_percol*, int64_t ncols, float* v
                     int nthreads);
 
 /* Build-defined stable-dt bound (no reference counterpart):
- * min over cells of C*dz^2/max(D_w, D_T). Returns the min over the batch. */
+ * courant*dz^2 / max over faces of the face diffusivities (see the .inc).
+ * Returns the min over the batch. */
 double lho_stable_dt_f64(const lho_model*, const lho_percol*, int64_t ncols, const double* vl,
-                         const double* ti, const double* rhoe, int64_t lev_stride,
-                         int64_t col_stride, double courant);
+                         const double* ti, const double* rhoe, const double* T_aux,
+                         int64_t lev_stride, int64_t col_stride, double courant);
 double lho_stable_dt_f32(const lho_model*, const lho_percol*, int64_t ncols, const float* vl,
-                         const float* ti, const float* rhoe, int64_t lev_stride,
-                         int64_t col_stride, double courant);
+                         const float* ti, const float* rhoe, const float* T_aux,
+                         int64_t lev_stride, int64_t col_stride, double courant);
 
 int lho_openmp_max_threads(void);
 

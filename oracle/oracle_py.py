@@ -151,7 +151,7 @@ def _declare(L):
         sig("lho_diagnostics", C.c_int, [mp, pcp, i64, P, P, P, P, P, P, P, P, i64, i64])
         sig("lho_ssprk33", C.c_int, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double, C.c_double,
                                      i64, _DP, C.c_int])
-        sig("lho_stable_dt", C.c_double, [mp, pcp, i64, P, P, P, i64, i64, C.c_double])
+        sig("lho_stable_dt", C.c_double, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double])
     L.lho_openmp_max_threads.restype = C.c_int
 
 
@@ -318,15 +318,15 @@ def ssprk33(om: OracleModel, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None
         raise ValueError(f"oracle ssprk33 failed (code {rc})")
 
 
-def stable_dt(om: OracleModel, vl, ti, rhoe=None, courant=0.5):
+def stable_dt(om: OracleModel, vl, ti, rhoe=None, courant=0.5, T_aux=None):
     dtype = vl.dtype
     ft = _ft(dtype)
     ls, cs = _strides(vl)
     m = om.c_model()
     pc, keep = om.c_percol()
     r = fn("lho_stable_dt", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
-                                   vl.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft), ls, cs,
-                                   float(courant))
+                                   vl.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
+                                   _ptr(T_aux, ft), ls, cs, float(courant))
     del keep
     return r
 

@@ -192,6 +192,30 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         rho_c_s = sp.rho_c_ds + tl * (e.cp_l * e.rho_liq) + ti * (e.cp_i * e.rho_ice)
         rhoe = rho_c_s * (T - e.T_0) - ti * e.rho_ice * e.LH_f0
         return Case(name, om, dt, N, vl=vl.astype(dt), ti=ti.astype(dt), rhoe=rhoe.astype(dt))
+    if name in ("mixed_smooth_f64", "mixed_smooth_f32"):
+        # steppable variant of the above: smooth fields with ice lenses, saturated
+        # zones, both conductivity factors, Dirichlet top / free drainage bottom
+        n, N = 48, ncols or 200
+        dt = f32 if name.endswith("f32") else f64
+        sp, vg = coupled_soil()
+        bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.42),
+              (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0),
+              (O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 276.0),
+              (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_FLUX, 0.05)}
+        om = O.OracleModel(O.MODEL_COUPLED, n, -2.4, 0.0, soil=sp, vg=vg, bc=bc,
+                           cf=O.default_cf(viscosity=True, impedance=True))
+        c = np.arange(N)
+        zc, _ = O.grid(-2.4, 0.0, n)
+        ph = 6.28 * uhash(c, 21, n)[:, None]
+        ti = np.where(uhash(c, 22, n)[:, None] < 0.5,
+                      0.06 * np.maximum(0.0, np.sin(3.0 * zc[None, :] + ph)), 0.0)
+        vl = 0.30 + 0.14 * np.sin(2.0 * zc[None, :] + ph) + 0.09 * uhash(c, 23, n)[:, None]
+        T = 278.0 + 6.0 * np.cos(1.5 * zc[None, :] + ph)
+        e = om.earth
+        tl = np.minimum(vl, sp.nu - ti)
+        rho_c_s = sp.rho_c_ds + tl * (e.cp_l * e.rho_liq) + ti * (e.cp_i * e.rho_ice)
+        rhoe = rho_c_s * (T - e.T_0) - ti * e.rho_ice * e.LH_f0
+        return Case(name, om, dt, N, vl=vl.astype(dt), ti=ti.astype(dt), rhoe=rhoe.astype(dt))
     if name == "richards_viscosity_f64":
         n, N = 50, ncols or 130
         om = O.OracleModel(O.MODEL_RICHARDS, n, -10.0, 0.0,

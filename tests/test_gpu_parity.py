@@ -24,7 +24,8 @@ def cw(case, math="fast"):
 
 CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128",
          "c3_coupled_f32", "c3_coupled_f64", "c5_percol_f64", "heat_dirichlet_f64",
-         "heat_dirichlet_f32", "mixed_factors_f64", "mixed_factors_f32", "richards_viscosity_f64",
+         "heat_dirichlet_f32", "mixed_factors_f64", "mixed_factors_f32", "mixed_smooth_f64", "mixed_smooth_f32",
+         "richards_viscosity_f64",
          "single_cell_f64"]
 
 
