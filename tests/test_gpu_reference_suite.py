@@ -1,0 +1,210 @@
+"""The reference's own tests, re-expressed on the host mirror of its API
+(landhydrology.jl_amd: SoilModel, make_rhs, initialize_states, Simulation, ...) so
+they read like test/SoilModel/*.jl.  Everything numerical runs in the HIP library.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as g
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lh():
+    return g.load_package()
+
+
+def coupled_params(lh, FT=np.float64):
+    sp, vg = pc.coupled_soil()
+    msp = lh.SoilParams(FT, ν=sp.nu, S_s=sp.S_s, ν_ss_gravel=0.0, ν_ss_om=0.0, ν_ss_quartz=0.92,
+                        ρc_ds=sp.rho_c_ds, κ_solid=sp.kappa_solid,
+                        κ_sat_unfrozen=sp.kappa_sat_unfrozen, κ_sat_frozen=sp.kappa_sat_frozen)
+    hm = lh.vanGenuchten(FT, n=2.0, α=2.6, Ksat=0.0443 / 3600 / 100, θr=0.0)
+    return msp, hm
+
+
+def test_default_ic_and_single_rhs(lh):
+    """test/SoilModel/coupled.jl:123-234 ("test default ic")."""
+    FT = np.float64
+    msp, hm = coupled_params(lh)
+    domain = lh.Column(FT, zlim=(-2.0, 0.0), nelements=20)
+    bc = lh.SoilColumnBC(
+        top=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0), energy=lh.VerticalFlux(0.0)),
+        bottom=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0), energy=lh.VerticalFlux(0.0)))
+    param_set = lh.EarthParameterSet()
+    soil_model = lh.SoilModel(FT, domain=domain, energy_model=lh.SoilEnergyModel(),
+                              hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                              boundary_conditions=bc, soil_param_set=msp,
+                              earth_param_set=param_set)
+    Y_init, Ya_init = lh.default_initial_conditions(soil_model)
+    want_z = np.array([(-195 + 10 * i) / 100 for i in range(20)])
+    assert np.allclose(Ya_init.zc, want_z, rtol=0, atol=4.5e-16)            # :198
+    assert np.allclose(Y_init.soil.ϑ_l[0], 0.25)                            # :199
+    assert np.allclose(Y_init.soil.θ_i[0], 0.0)                             # :200
+    T0 = param_set.T_0
+    rho_c_s = msp.rho_c_ds + 0.25 * (param_set.cp_l * param_set.rho_cloud_liq)
+    assert np.allclose(Y_init.soil.ρe_int[0], rho_c_s * (273.16 - T0))      # :217
+    dY = Y_init.similar()
+    soil_rhs = lh.make_rhs(soil_model)
+    assert soil_rhs(dY, Y_init, Ya_init, 0.0) is dY                          # returns dY (:41)
+    assert np.allclose(dY.soil.θ_i[0], 0.0, atol=0)                          # :221
+    assert np.allclose(dY.soil.ρe_int[0], 0.0, atol=1e-12)                   # :222
+    S = pc.O.fn("lho_effective_saturation", FT)(0.5, 0.25, 0.0)
+    K = pc.O.fn("lho_hydraulic_conductivity", FT)(pc.coupled_soil()[1], S, 1.0, 1.0)
+    flux = np.zeros(21) - K
+    flux[0] = flux[-1] = 0.0
+    minus_div = -(flux[1:] - flux[:-1]) / 0.1
+    assert np.sum(dY.soil.ϑ_l[0] - minus_div) < np.finfo(FT).eps            # :234
+    assert np.allclose(dY.soil.ϑ_l[0], minus_div, rtol=1e-12, atol=1e-20)
+    # models without a default IC raise (models.jl:164-166)
+    m2 = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                      hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                      boundary_conditions=bc, soil_param_set=msp, earth_param_set=param_set)
+    with pytest.raises(RuntimeError):
+        lh.default_initial_conditions(m2)
+
+
+def test_empty_rhs_and_update_aux(lh):
+    """test/SoilModel/test_rhs.jl:1-46: prescribed/prescribed model."""
+    FT = np.float64
+    domain = lh.Column(FT, zlim=(-2.0, 0.0), nelements=20)
+    Tp = lambda z, t: 10.0 * z + t
+    vlp = lambda z, t: 10.0 * z * t
+    tip = lambda z, t: 0.0 * z
+    soil_model = lh.SoilModel(FT, domain=domain,
+                              energy_model=lh.PrescribedTemperatureModel(T_profile=Tp),
+                              hydrology_model=lh.PrescribedHydrologyModel(ϑ_l_profile=vlp,
+                                                                          θ_i_profile=tip),
+                              boundary_conditions=None, earth_param_set=None)
+    Y, p = lh.initialize_states(soil_model, lambda z, m: {}, 0.0)
+    soil_rhs = lh.make_rhs(soil_model)
+    dY = dict(Y)
+    soil_rhs(dY, Y, p, 0.0)
+    assert dY == Y                                                           # :32
+    t = 10.0
+    lh.make_update_aux(soil_model.energy_model)(p, t)
+    lh.make_update_aux(soil_model.hydrology_model)(p, t)
+    z = np.asarray(p.zc)
+    assert np.allclose(p.soil.T, Tp(z, t))                                   # :39
+    assert np.allclose(p.soil.θ_l, vlp(z, t))                                # :40 (ϑ_l)
+    assert np.allclose(p.soil.θ_i, tip(z, t))                                # :41
+
+
+def test_heat_analytic_through_simulation(lh):
+    """test/SoilModel/heat_test_interface.jl:1-100 via Simulation/step!/run!."""
+    FT = np.float64
+    msp = lh.SoilParams(FT, ν=0.495, ν_ss_gravel=0.1, ν_ss_om=0.1, ν_ss_quartz=0.1,
+                        ρc_ds=0.43314518988433487, κ_solid=8.0, κ_sat_unfrozen=0.57,
+                        κ_sat_frozen=2.29)
+    t0, tf, dt, n = 0.0, 2.0, 1e-4, 60
+    domain = lh.Column(FT, zlim=(0.0, 1.0), nelements=n)
+    A, omega = 5.0, 2 * math.pi
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(energy=lh.Dirichlet(lambda t: 0.0)),
+                         bottom=lh.SoilComponentBC(energy=lh.Dirichlet(
+                             lambda t: A * math.cos(omega * t))))
+    param_set = lh.EarthParameterSet()
+    soil_model = lh.SoilModel(FT, domain=domain, energy_model=lh.SoilEnergyModel(),
+                              hydrology_model=lh.PrescribedHydrologyModel(),
+                              boundary_conditions=bc, soil_param_set=msp,
+                              earth_param_set=param_set)
+    with pytest.raises(RuntimeError):
+        lh.default_initial_conditions(soil_model)                           # :55
+
+    def energy_ic(z, model):
+        rho_c_s = model.soil_param_set.rho_c_ds          # theta_l = theta_i = 0
+        return {"ρe_int": rho_c_s * (0.0 - model.earth_param_set.T_0) + 0.0 * z}
+
+    Y, Ya = lh.initialize_states(soil_model, energy_ic, t0)
+    sim = lh.Simulation(soil_model, lh.SSPRK33(), Y_init=Y, dt=dt, tspan=(t0, tf), Ya_init=Ya,
+                        saveat=60 * dt)
+    assert lh.step(sim) is None                                              # :83
+    lh.run(sim)
+    sol = sim.integrator.sol
+    assert abs(sol.t[-1] - tf) < 1e-9
+    z = np.asarray(Ya.zc, dtype=np.float64)
+    s = math.sqrt(omega / 2) * (1 + 1j)
+    analytic = np.real((np.exp(s * (1 - z)) - np.exp(-s * (1 - z))) * A * np.exp(1j * omega * tf)
+                       / (np.exp(s) - np.exp(-s)))
+    Tfinal = param_set.T_0 + sol.u[-1]["ρe_int"][0] / msp.rho_c_ds
+    assert np.mean((analytic - Tfinal) ** 2) < 1e-6                          # :99
+
+
+def test_richards_sand_alternate_bc_through_simulation(lh):
+    """test/SoilModel/richards_equation.jl:98-173 setup through the mirror API
+    (Dirichlet top state, FreeDrainage bottom), first 5 minutes; compared with the
+    oracle since the reference's data file is a download."""
+    FT = np.float64
+    msp = lh.SoilParams(FT, ν=0.287, S_s=1e-3)
+    hm = lh.vanGenuchten(FT, n=3.96, α=2.7, Ksat=34 / 3600 / 100, θr=0.075)
+    domain = lh.Column(FT, zlim=(-1.5, 0.0), nelements=150)
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.Dirichlet(lambda t: 0.267)),
+                         bottom=lh.SoilComponentBC(hydrology=lh.FreeDrainage()))
+    soil_model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                              hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                              boundary_conditions=bc, soil_param_set=msp,
+                              earth_param_set=lh.EarthParameterSet())
+    Y, Ya = lh.initialize_states(soil_model, lambda z, m: {"ϑ_l": 0.1, "θ_i": 0.0}, 0.0)
+    sim = lh.Simulation(soil_model, lh.SSPRK33(), Y_init=Y, dt=0.25, tspan=(0.0, 300.0),
+                        Ya_init=Ya, saveat=60 * 0.25)
+    assert lh.step(sim) is None
+    lh.run(sim)
+    vl = sim.integrator.sol.u[-1]["ϑ_l"]
+    O = pc.O
+    om = O.OracleModel(O.MODEL_RICHARDS, 150, -1.5, 0.0, soil=O.default_soil(nu=0.287, S_s=1e-3),
+                       vg=O.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075),
+                       bc={(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.267),
+                           (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)})
+    w = np.full((1, 150), 0.1)
+    O.ssprk33(om, 0.25, 1200, vl=w, ti=np.zeros((1, 150)))
+    assert np.max(np.abs(vl - w) / w) < 1e-6                                 # north star
+    assert len(sim.integrator.sol.t) == 1 + 20 + 1 or len(sim.integrator.sol.t) >= 20
+
+
+def test_ensemble_extension_and_per_column_parameters(lh):
+    """Build extension: Column(..., ncolumns=N) with per-column van Genuchten
+    parameters and per-column flux BCs (BASELINE config 5) through the mirror."""
+    FT = np.float64
+    case = pc.make_case("c5_percol_f64", ncols=257)
+    pcol = case.om.percol
+    hm = lh.vanGenuchten(FT, n=pcol["vg_n"], α=pcol["vg_alpha"], Ksat=pcol["vg_Ksat"],
+                         θr=pcol["vg_theta_r"])
+    msp = lh.SoilParams(FT, ν=pcol["nu"])
+    domain = lh.Column(FT, zlim=(-2.56, 0.0), nelements=128, ncolumns=257)
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.VerticalFlux(-0.5 * pcol["vg_Ksat"])),
+                         bottom=lh.SoilComponentBC(hydrology=lh.FreeDrainage()))
+    model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                         hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                         boundary_conditions=bc, soil_param_set=msp,
+                         earth_param_set=lh.EarthParameterSet())
+    Y, Ya = lh.initialize_states(model, lambda z, m: {"ϑ_l": case.vl, "θ_i": case.ti}, 0.0)
+    dY = Y.similar()
+    lh.make_rhs(model)(dY, Y, Ya, 0.0)
+    want = pc.run_oracle_rhs(case)
+    pc.assert_tendencies_close(case, {"vl": dY.soil.ϑ_l, "ti": dY.soil.θ_i}, want, 4.0)
+
+
+def test_error_behaviour(lh):
+    FT = np.float64
+    domain = lh.Column(FT, zlim=(-1.0, 0.0), nelements=8)
+    # NoBC on a dynamic component: the reference cannot build SetValue(nothing)
+    m = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                     hydrology_model=lh.SoilHydrologyModel(FT),
+                     boundary_conditions=lh.SoilColumnBC(), earth_param_set=lh.EarthParameterSet())
+    Y, Ya = lh.initialize_states(m, lambda z, mm: {"ϑ_l": 0.2, "θ_i": 0.0}, 0.0)
+    with pytest.raises(lh.ModelError):
+        lh.make_rhs(m)(Y.similar(), Y, Ya, 0.0)
+    # IC with the wrong variables
+    with pytest.raises(KeyError):
+        lh.initialize_states(m, lambda z, mm: {"ρe_int": 0.0}, 0.0)
+    # Simulation without Y_init hits the reference's own bug (simulation.jl:50)
+    with pytest.raises(NameError):
+        lh.Simulation(m, lh.SSPRK33(), Y_init=None, dt=1.0, tspan=(0, 1), Ya_init=None)
+    # FT mismatch between domain and model
+    with pytest.raises(TypeError):
+        lh.SoilModel(np.float32, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                     hydrology_model=lh.SoilHydrologyModel(np.float32),
+                     boundary_conditions=lh.SoilColumnBC(), earth_param_set=None)
