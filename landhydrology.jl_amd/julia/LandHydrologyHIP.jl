@@ -1,0 +1,262 @@
+# LandHydrologyHIP.jl -- the reference-side binding a LandHydrology.jl maintainer
+# would add to route `make_rhs(model)` / `Simulation` through liblandhydro_hip.so.
+#
+# STATUS: text only.  Julia is not installed in the build image, so this file has
+# never been executed; it documents the ccall surface one-to-one with
+# include/landhydro.h.  The tested host binding is the Python mirror
+# (landhydrology.jl_amd/soil.py), which makes exactly these calls through ctypes.
+#
+# Usage sketch (single column, exactly the reference's API):
+#
+#   using LandHydrology, LandHydrologyHIP
+#   rhs! = make_rhs(soil_model, HIPBackend())          # same 4-argument closure
+#   prob = ODEProblem(rhs!, Y, (t0, tf), Ya)            # Y, Ya: host FieldVectors
+#
+# Ensemble use keeps the state on the device:
+#
+#   ens  = ColumnEnsemble(soil_model, ncolumns)          # lh_create + parameters
+#   Y    = upload(ens, ϑ_l = A1, θ_i = A2)              # [nelements, ncolumns] arrays
+#   step_ssprk33!(ens, Y, nothing, t, dt, nsteps)
+#
+module LandHydrologyHIP
+
+using LandHydrology
+using LandHydrology.SoilInterface
+using LandHydrology.SoilInterface: SoilModel, SoilEnergyModel, SoilHydrologyModel,
+    PrescribedTemperatureModel, PrescribedHydrologyModel, NoBC, VerticalFlux, Dirichlet,
+    FreeDrainage, SoilComponentBC
+using LandHydrology.SoilInterface.SoilWaterParameterizations:
+    NoEffect, TemperatureDependentViscosity, IceImpedance
+using CLIMAParameters.Planet: ρ_cloud_liq, ρ_cloud_ice, cp_l, cp_i, T_0, LH_f0
+using CLIMAParameters.Atmos.Microphysics: K_therm
+import LandHydrology.SoilInterface: make_rhs
+
+export HIPBackend, ColumnEnsemble, upload, download, step_ssprk33!, stable_dt
+
+const lib = get(ENV, "LANDHYDRO_HIP_LIB", "liblandhydro_hip.so")
+
+# ---- mirrors of the C structs (include/landhydro.h) -------------------------
+struct lh_config
+    ncols::Int64
+    nlev::Int32
+    dtype::Int32        # LH_F32 = 0, LH_F64 = 1
+    zmin::Float64
+    zmax::Float64
+    model::Int32        # RICHARDS = 0, HEAT = 1, COUPLED = 2
+    device::Int32
+    stream::Ptr{Cvoid}
+end
+struct lh_earth_params
+    rho_liq::Float64; rho_ice::Float64; cp_l::Float64; cp_i::Float64
+    T_0::Float64; LH_f0::Float64; K_therm::Float64
+end
+struct lh_soil_params
+    nu::Float64; S_s::Float64; nu_ss_gravel::Float64; nu_ss_om::Float64; nu_ss_quartz::Float64
+    rho_c_ds::Float64; kappa_solid::Float64; rho_p::Float64; kappa_sat_unfrozen::Float64
+    kappa_sat_frozen::Float64; a::Float64; b::Float64; kappa_dry_parameter::Float64
+end
+struct lh_vg_params
+    n::Float64; alpha::Float64; theta_r::Float64; Ksat::Float64
+end
+
+const LH_BC_NONE, LH_BC_FLUX, LH_BC_DIRICHLET, LH_BC_FREE_DRAINAGE = Int32(0), Int32(1), Int32(2), Int32(3)
+const LH_FACE_BOTTOM, LH_FACE_TOP = Int32(0), Int32(1)
+const LH_COMP_ENERGY, LH_COMP_HYDROLOGY = Int32(0), Int32(1)
+const LH_VAR = (ϑ_l = Int32(0), θ_i = Int32(1), ρe_int = Int32(2), T = Int32(3))
+
+struct HIPBackend
+    device::Int32
+end
+HIPBackend() = HIPBackend(Int32(-1))
+
+# every entry point returns a status; non-zero becomes error(msg) like the
+# reference's ArgumentError / error(...) paths (boundary_conditions.jl:188,524)
+function check(ctx, rc)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:lh_last_error, lib), Cstring, (Ptr{Cvoid},), ctx))
+    error("landhydro_hip [$rc]: $msg")
+end
+
+model_kind(::PrescribedTemperatureModel, ::SoilHydrologyModel) = Int32(0)
+model_kind(::SoilEnergyModel, ::PrescribedHydrologyModel) = Int32(1)
+model_kind(::SoilEnergyModel, ::SoilHydrologyModel) = Int32(2)
+
+bc_kind(::NoBC) = LH_BC_NONE
+bc_kind(::VerticalFlux) = LH_BC_FLUX
+bc_kind(::Dirichlet) = LH_BC_DIRICHLET
+bc_kind(::FreeDrainage) = LH_BC_FREE_DRAINAGE
+bc_value(bc::VerticalFlux, t) = Float64(bc.flux)
+bc_value(bc::Dirichlet, t) = Float64(bc.state_value(t))
+bc_value(::Any, t) = 0.0
+
+"""
+    ColumnEnsemble(model::SoilModel{FT}, ncolumns; backend = HIPBackend())
+
+`ncolumns` independent copies of `model.domain` on one device (lh_create +
+parameter setters).  Everything `SoilModel` holds maps to one setter call.
+"""
+mutable struct ColumnEnsemble{FT, M <: SoilModel}
+    ctx::Ptr{Cvoid}
+    model::M
+    ncolumns::Int
+end
+
+function ColumnEnsemble(model::SoilModel{FT}, ncolumns::Integer; backend = HIPBackend()) where {FT}
+    d = model.domain
+    cfg = Ref(lh_config(ncolumns, d.nelements, FT == Float64 ? 1 : 0, d.zlim[1], d.zlim[2],
+                        model_kind(model.energy_model, model.hydrology_model), backend.device, C_NULL))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:lh_create, lib), Cint, (Ptr{Ptr{Cvoid}}, Ptr{lh_config}), ctx, cfg)
+    rc == 0 || check(C_NULL, rc)
+    ens = ColumnEnsemble{FT, typeof(model)}(ctx[], model, ncolumns)
+    finalizer(e -> ccall((:lh_destroy, lib), Cint, (Ptr{Cvoid},), e.ctx), ens)
+    ps = model.earth_param_set
+    if ps !== nothing && !(model.energy_model isa PrescribedTemperatureModel)
+        ep = Ref(lh_earth_params(ρ_cloud_liq(ps), ρ_cloud_ice(ps), cp_l(ps), cp_i(ps), T_0(ps),
+                                 LH_f0(ps), K_therm(ps)))
+        check(ens.ctx, ccall((:lh_set_earth_params, lib), Cint, (Ptr{Cvoid}, Ptr{lh_earth_params}), ens.ctx, ep))
+    end
+    sp = model.soil_param_set
+    s = Ref(lh_soil_params(sp.ν, sp.S_s, sp.ν_ss_gravel, sp.ν_ss_om, sp.ν_ss_quartz, sp.ρc_ds,
+                           sp.κ_solid, sp.ρp, sp.κ_sat_unfrozen, sp.κ_sat_frozen, sp.a, sp.b,
+                           sp.κ_dry_parameter))
+    check(ens.ctx, ccall((:lh_set_soil_params, lib), Cint, (Ptr{Cvoid}, Ptr{lh_soil_params}), ens.ctx, s))
+    hy = model.hydrology_model
+    if hy isa SoilHydrologyModel
+        hm = hy.hydraulic_model
+        v = Ref(lh_vg_params(hm.n, hm.α, hm.θr, hm.Ksat))
+        check(ens.ctx, ccall((:lh_set_vg_params, lib), Cint, (Ptr{Cvoid}, Ptr{lh_vg_params}), ens.ctx, v))
+        vf, imf = hy.viscosity_factor, hy.impedance_factor
+        vk = vf isa TemperatureDependentViscosity
+        ik = imf isa IceImpedance
+        check(ens.ctx, ccall((:lh_set_conductivity_factors, lib), Cint,
+                             (Ptr{Cvoid}, Int32, Float64, Float64, Int32, Float64), ens.ctx,
+                             Int32(vk), vk ? vf.γ : 2.64e-2, vk ? vf.T_ref : 288.0, Int32(ik),
+                             ik ? imf.Ω : 7.0))
+    end
+    set_bcs!(ens, 0.0)
+    return ens
+end
+
+# Dirichlet.state_value and friends are Julia closures of t
+# (boundary_conditions.jl:61-64): evaluate on the host, pass numbers.
+function set_bcs!(ens::ColumnEnsemble, t)
+    bcs = ens.model.boundary_conditions
+    for (face, fbc) in ((LH_FACE_BOTTOM, bcs.bottom), (LH_FACE_TOP, bcs.top))
+        fbc isa SoilComponentBC || error("PrescribedAtmosForcing is outside the accelerated path")
+        for (comp, bc) in ((LH_COMP_ENERGY, fbc.energy), (LH_COMP_HYDROLOGY, fbc.hydrology))
+            check(ens.ctx, ccall((:lh_set_bc, lib), Cint,
+                                 (Ptr{Cvoid}, Int32, Int32, Int32, Float64, Ptr{Float64}),
+                                 ens.ctx, face, comp, bc_kind(bc), bc_value(bc, t), C_NULL))
+        end
+    end
+end
+
+mutable struct DeviceState
+    ens::ColumnEnsemble
+    handle::Ptr{Cvoid}
+end
+
+function new_state(ens::ColumnEnsemble, mask::UInt32 = UInt32(0))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ens.ctx, ccall((:lh_state_create, lib), Cint, (Ptr{Cvoid}, UInt32, Ptr{Ptr{Cvoid}}), ens.ctx, mask, h))
+    st = DeviceState(ens, h[])
+    finalizer(s -> ccall((:lh_state_destroy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ens.ctx, s.handle), st)
+    return st
+end
+
+# A is [nelements, ncolumns], column-major: level-fastest per column, exactly
+# `parent(field)` of the reference when ncolumns == 1 (coupled.jl:198-200).
+function upload!(st::DeviceState, var::Symbol, A::AbstractMatrix{FT}) where {FT}
+    check(st.ens.ctx, ccall((:lh_upload, lib), Cint,
+                            (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64),
+                            st.ens.ctx, st.handle, LH_VAR[var], A, 1, size(A, 1)))
+end
+function download!(A::AbstractMatrix{FT}, st::DeviceState, var::Symbol) where {FT}
+    check(st.ens.ctx, ccall((:lh_download, lib), Cint,
+                            (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64),
+                            st.ens.ctx, st.handle, LH_VAR[var], A, 1, size(A, 1)))
+    return A
+end
+function upload(ens::ColumnEnsemble; fields...)
+    st = new_state(ens)
+    for (k, A) in fields
+        upload!(st, k, A)
+    end
+    return st
+end
+download(st::DeviceState, var::Symbol, ::Type{FT}) where {FT} =
+    download!(Matrix{FT}(undef, st.ens.model.domain.nelements, st.ens.ncolumns), st, var)
+
+"rhs!(dY, Y, Ya, t) on device states (right_hand_side.jl:37-42)"
+function rhs!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t)
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_rhs, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                         ens.ctx, t, Y.handle, ya, dY.handle))
+    return dY
+end
+
+"solve(prob, SSPRK33(), dt = dt) for `nsteps` steps, state stays on the device (simulation.jl:58-87)"
+function step_ssprk33!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt, nsteps)
+    # Dirichlet closures at the stage times t, t+dt, t+dt/2 -> [4, 3, nsteps] doubles
+    bcs = ens.model.boundary_conditions
+    vals = Array{Float64}(undef, 2, 2, 3, nsteps)      # (component, face, stage, step), C order reversed
+    for s in 1:nsteps, (k, off) in enumerate((0.0, dt, dt / 2))
+        ts = t + (s - 1) * dt + off
+        for (f, fbc) in enumerate((bcs.bottom, bcs.top)), (c, bc) in enumerate((fbc.energy, fbc.hydrology))
+            vals[c, f, k, s] = bc_value(bc, ts)
+        end
+    end
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_step_ssprk33, lib), Cint,
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Float64}),
+                         ens.ctx, Y.handle, ya, t, dt, nsteps, vals))
+    return Y
+end
+
+function stable_dt(ens::ColumnEnsemble, Y::DeviceState, Ya = nothing; courant = 0.5)
+    out = Ref{Float64}(0.0)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_stable_dt, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Float64}),
+                         ens.ctx, Y.handle, ya, courant, out))
+    return out[]
+end
+
+"""
+    make_rhs(model::SoilModel, ::HIPBackend)
+
+Drop-in for `make_rhs(model)` (right_hand_side.jl:33-44): returns a closure with
+the same `rhs!(dY, Y, Ya, t) -> dY` signature working on the reference's host
+`FieldVector`s (one column).  Each call uploads Y (and the prescribed fields of
+Ya), runs lh_rhs and downloads dY, so it is a correctness bridge for existing
+scripts; throughput comes from `ColumnEnsemble` + `step_ssprk33!`, where the state
+never leaves the device.
+"""
+function make_rhs(model::SoilModel{FT}, backend::HIPBackend) where {FT}
+    ens = ColumnEnsemble(model, 1; backend = backend)
+    update_aux_en! = LandHydrology.SoilInterface.make_update_aux(model.energy_model)
+    update_aux_hydr! = LandHydrology.SoilInterface.make_update_aux(model.hydrology_model)
+    Yd, dYd = new_state(ens), new_state(ens)
+    Yad = nothing
+    function rhs!(dY, Y, Ya, t)
+        update_aux_en!(Ya, t)
+        update_aux_hydr!(Ya, t)
+        ys = getproperty(Y, model.name)
+        for k in propertynames(ys)
+            upload!(Yd, k, reshape(parent(getproperty(ys, k)), :, 1))
+        end
+        # prescribed fields the device reads: T (viscosity) or (ϑ_l, θ_i) (heat-only)
+        # are uploaded into Yad the same way from getproperty(Ya, model.name)
+        rhs!(ens, dYd, Yd, Yad, t)
+        ds = getproperty(dY, model.name)
+        for k in propertynames(ds)
+            download!(reshape(parent(getproperty(ds, k)), :, 1), dYd, k)
+        end
+        return dY
+    end
+    return rhs!
+end
+
+end # module
