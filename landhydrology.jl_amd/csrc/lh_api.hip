@@ -16,6 +16,11 @@
 
 using namespace lh;
 
+// default address stagger between consecutively allocated planes (bytes)
+#ifndef LH_PLANE_STAGGER
+#define LH_PLANE_STAGGER 0 /* no consistent gain measured (profiles/round1_tune_plane_stagger.txt): placement noise is +-5 % */
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -37,7 +42,8 @@ struct HostParams {
 struct lh_state {
     lh_ctx* ctx;
     uint32_t mask;
-    void* plane[LH_NVARS];
+    void* plane[LH_NVARS]; // what kernels address
+    void* raw[LH_NVARS];   // what hipMalloc returned (plane = raw + stagger)
 };
 
 struct lh_ctx {
@@ -58,6 +64,7 @@ struct lh_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int math = MATH_FAST;
     Tune tune;
+    unsigned plane_counter = 0;
     std::vector<double> zc_host;
     std::string err;
     std::vector<lh_state*> states;
@@ -165,6 +172,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_por = FT(1) / (u.nu - u.theta_r);
     u.inv_S_s = FT(1) / u.S_s;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
+    if (!(u.nu > u.theta_r)) u.Ksat = u.inv_S_s = u.log2_alpha = u.alpha_pnn = FT(NAN);
     {
         FT rho_b = (FT(1) - u.nu) * P.rho_p;
         FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -193,6 +201,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
     if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;
+    if ((q = strstr(t, "pad=")) && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
 }
 
 bool any_percol(const lh_ctx* c) {
@@ -283,16 +292,23 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
     s->ctx = c;
     s->mask = mask;
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+    // Planes that are streamed together (Y, dY, stage states) are staggered in
+    // the address space: large allocations come back 2-MiB aligned, so the same
+    // (level, column) of every plane would otherwise share its low address bits
+    // -- and with them HBM channel and bank -- in all concurrent streams.
+    const size_t pad = c->tune.pad >= 0 ? size_t(c->tune.pad) : LH_PLANE_STAGGER;
     for (int i = 0; i < LH_NVARS; ++i) {
-        s->plane[i] = nullptr;
+        s->plane[i] = s->raw[i] = nullptr;
         if (mask & (1u << i)) {
-            hipError_t e = hipMalloc(&s->plane[i], bytes);
+            const size_t shift = pad * size_t(c->plane_counter++ % 8);
+            hipError_t e = hipMalloc(&s->raw[i], bytes + 8 * pad);
             if (e != hipSuccess) {
                 for (int j = 0; j < i; ++j)
-                    if (s->plane[j]) (void)hipFree(s->plane[j]);
+                    if (s->raw[j]) (void)hipFree(s->raw[j]);
                 delete s;
                 return fail(c, LH_ENOMEM, "hipMalloc of a %zu-byte plane failed: %s", bytes, hipGetErrorString(e));
             }
+            s->plane[i] = static_cast<char*>(s->raw[i]) + shift;
             e = hipMemsetAsync(s->plane[i], 0, bytes, c->stream);
             if (e != hipSuccess) return fail(c, LH_ENODEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
         }
@@ -304,7 +320,7 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
 
 void state_free(lh_ctx* c, lh_state* s) {
     for (int i = 0; i < LH_NVARS; ++i)
-        if (s->plane[i]) (void)hipFree(s->plane[i]);
+        if (s->raw[i]) (void)hipFree(s->raw[i]);
     for (size_t i = 0; i < c->states.size(); ++i)
         if (c->states[i] == s) {
             c->states.erase(c->states.begin() + i);
@@ -350,6 +366,7 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
     if (!out || !cfg) return fail(nullptr, LH_EINVAL, "lh_create: NULL argument");
     *out = nullptr;
     if (cfg->ncols < 1 || cfg->nlev < 1) return fail(nullptr, LH_EINVAL, "lh_create: ncols and nlev must be >= 1");
+    if (cfg->nlev > 4096) return fail(nullptr, LH_EINVAL, "lh_create: nlev > 4096 is not supported (level coordinates are staged in LDS)");
     if (!(cfg->zmin < cfg->zmax)) return fail(nullptr, LH_EINVAL, "lh_create: zlim[1] < zlim[2] required (domain.jl:30)");
     if (cfg->dtype != LH_F32 && cfg->dtype != LH_F64) return fail(nullptr, LH_EINVAL, "lh_create: dtype must be LH_F32 or LH_F64");
     if (cfg->model < LH_MODEL_RICHARDS || cfg->model > LH_MODEL_COUPLED) return fail(nullptr, LH_EINVAL, "lh_create: unknown model");

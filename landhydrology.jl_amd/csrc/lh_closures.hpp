@@ -11,6 +11,18 @@
 
 namespace lh {
 
+// A non-positive saturation (nu <= theta_r) makes `^` raise DomainError in the
+// reference; here the column's K and psi become NaN (and the status flag is set)
+template <typename FT>
+__host__ __device__ inline void poison_invalid(ColC<FT>& c) {
+    if (!(c.nu > c.theta_r)) {
+        c.Ksat = FT(NAN);
+        c.inv_S_s = FT(NAN);
+        c.log2_alpha = FT(NAN);
+        c.alpha_pnn = FT(NAN);
+    }
+}
+
 template <typename FT, typename M>
 __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t col, bool percol) {
     if (!percol) return P.uc;
@@ -37,6 +49,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.inv_por = FT(1) / (c.nu - c.theta_r);
     c.inv_S_s = FT(1) / c.S_s;
     c.log2_alpha = MathLibm<FT>::log2(alpha);
+    poison_invalid(c);
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
     FT rho_b = (FT(1) - c.nu) * P.rho_p;
     FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;
@@ -114,7 +127,10 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     const FT num = vls - c.theta_r;
     const FT S = num * c.inv_por;
     const bool same = (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
-    const FT Se = same ? S : num * mm.rcp(nu_eff - c.theta_r);
+    FT Se = S;
+    if (__any(!same)) { // wave-uniform skip of the reciprocal when no lane has ice
+        if (!same) Se = num * mm.rcp(nu_eff - c.theta_r);
+    }
 
     FT Kr = FT(1), a = FT(0), Lw = FT(0);
     if (S < FT(1)) {
@@ -132,7 +148,8 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         if (P.impedance_kind) {
             FT tl = liquid_fraction(vl, nu_eff);
             FT f_i = ti / (tl + ti);
-            imp = FT(MathLibm<double>::pow(10.0, double(-P.Omega * f_i)));
+            // 10^(-Omega f_i) = 2^(-Omega f_i log2 10) on the production exp2
+            imp = mm.exp2((-P.Omega * f_i) * FT(3.3219280948873623));
         }
         K = K * visc * imp;
     }
@@ -151,8 +168,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             psi = (vl - nu_eff) * c.inv_S_s;
         }
     }
-    // a non-positive saturation (nu <= theta_r) is a DomainError in the reference
-    if (!(S > FT(0)) && !(S != S)) K = psi = FT(NAN);
+    // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>

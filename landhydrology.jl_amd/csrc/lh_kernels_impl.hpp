@@ -14,6 +14,23 @@
 
 namespace lh {
 
+// minimum waves per SIMD the register allocator must leave room for in the
+// column kernel (64 VGPRs): the kernel hides HBM latency by occupancy
+#ifndef LH_RHS_WAVES_PER_SIMD
+#define LH_RHS_WAVES_PER_SIMD 8
+#endif
+
+// The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
+// per-column / conductivity-factor variants and the libm debug policy keep what
+// they need (a bound there only produces scratch spills).
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
+constexpr int rhs_waves_per_simd() {
+    if (!M::is_production || FACTORS || PERCOL) return 1;
+    if (MODEL == MODEL_RICHARDS) return LH_RHS_WAVES_PER_SIMD;
+    if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
+    return 1;
+}
+
 // ----------------------------------------------------------------- helpers
 
 // native clang vectors (the nontemporal builtins do not take HIP_vector_type)
@@ -80,31 +97,51 @@ __device__ __forceinline__ bool finite(FT x) {
 //
 // MODE 0: write the tendency dY.
 // MODE 1..3: fused SSPRK33 stage s (OrdinaryDiffEq SSPRK33, Shu-Osher form):
-//   1: U1 = Y + dt f(Y)            (in = Y,  out = U1)
-//   2: U1 = (3 Y + U1 + dt f(U1))/4 (in = U1, base = Y, out = U1)
+//   1: U1 = Y + dt f(Y)              (in = Y,  out = U1)
+//   2: U1 = (3 Y + U1 + dt f(U1))/4  (in = U1, base = Y, out = U1)
 //   3: Y  = (Y + 2 U1 + 2 dt f(U1))/3 (in = U1, base = Y, out = Y)
-// with in/base/out planes handed over by the launcher.
+// In the fused stages theta_i is read from BASE (= Y) and never written: its
+// tendency is identically zero (right_hand_side.jl:182, :359), so every stage
+// value of theta_i equals Y's.
+//
+// Addressing: a uniform row pointer per plane (SGPRs, advanced by `stride` per
+// level) plus one 32-bit lane offset, so the loop carries no vector address
+// arithmetic.  The level coordinate z_i comes from LDS (staged once per block):
+// as a global load it would sit in the vector-memory queue behind the next
+// level's prefetch and force a full vmcnt(0) drain every level.
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
-    constexpr int CPL = CFG::CPL, PF = CFG::PF;
+    constexpr int CPL = CFG::CPL;
     constexpr bool NT = CFG::NT;
-    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 1];
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    FT* s_zc = reinterpret_cast<FT*>(s_dyn);
+    const int n = P.nlev;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_zc[i] = P.zc[i];
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
+    if (!M::uses_tables) __syncthreads();
+
     const int64_t col0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * CPL;
     if (col0 >= P.ncols) return;
     const int64_t stride = P.stride;
-    const int n = P.nlev;
+    const unsigned lane_off = (unsigned)col0; // a plane row is < 2^32 elements
 
-    // inputs: HEAT reads the prescribed water fields from Ya (right_hand_side.jl:200-201)
-    const FT* p_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + col0;
-    const FT* p_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : IN.v[1]) + col0;
-    const FT* p_re = HEAT ? IN.v[2] + col0 : nullptr;
+    // uniform row pointers (level 0); HEAT reads the prescribed water fields from
+    // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
+    const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]);
+    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (MODE == 0 ? IN.v[1] : BASE.v[1]));
+    const FT* r_re = HEAT ? IN.v[2] : nullptr;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
-    const FT* p_Ta = need_Taux ? AUX.v[3] + col0 : nullptr;
+    const FT* r_Ta = need_Taux ? AUX.v[3] : nullptr;
+    const FT* b_vl = (MODE >= 2 && WATER) ? BASE.v[0] : nullptr;
+    const FT* b_re = (MODE >= 2 && HEAT) ? BASE.v[2] : nullptr;
+    FT* o_vl = WATER ? OUT.v[0] : nullptr;
+    FT* o_ti = (WATER && MODE == 0) ? OUT.v[1] : nullptr;
+    FT* o_re = HEAT ? OUT.v[2] : nullptr;
 
     ColC<FT> c[CPL];
     int64_t colj[CPL]; // column index clamped into [0, ncols): pad lanes reuse the last column
@@ -114,60 +151,61 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         c[j] = make_colc<FT, M>(P, colj[j], PERCOL);
     }
 
-    FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];       // current cell inputs
-    FT vl_n[PF][CPL], ti_n[PF][CPL], re_n[PF][CPL], Ta_n[PF][CPL]; // levels in flight
-    FT vl_p[CPL], ti_p[CPL], re_p[CPL];          // previous cell inputs (fused stages)
+    FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
+    FT vl_n[CPL], ti_n[CPL], re_n[CPL], Ta_n[CPL]; // next level, in flight
+    FT vl_p[CPL], re_p[CPL];                       // previous cell inputs (fused stages)
     FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
-    bool bad = false;
+    FT nf_acc = FT(0); // += 0 * tendency: becomes NaN once any tendency is non-finite
 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         K_p[j] = h_p[j] = psi_p[j] = T_p[j] = kap_p[j] = E_p[j] = Fw_lo[j] = Fe_lo[j] = FT(0);
-        vl_p[j] = ti_p[j] = re_p[j] = FT(0);
-        vl[j] = ti[j] = re[j] = Ta[j] = FT(0);
+        vl_p[j] = re_p[j] = FT(0);
+        vl[j] = ti[j] = re[j] = FT(0);
+        re_n[j] = FT(0);
+        Ta[j] = Ta_n[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
     }
-    auto fetch = [&](int lev, int slot) {
-        const int64_t o = int64_t(lev) * stride;
-        vload<FT, CPL, NT>(p_vl + o, vl_n[slot]);
-        vload<FT, CPL, NT>(p_ti + o, ti_n[slot]);
-        if (HEAT) vload<FT, CPL, NT>(p_re + o, re_n[slot]);
-        if (need_Taux) vload<FT, CPL, NT>(p_Ta + o, Ta_n[slot]);
+    auto fetch = [&]() { // loads the level the row pointers currently address
+        vload<FT, CPL, NT>(r_vl + lane_off, vl_n);
+        vload<FT, CPL, NT>(r_ti + lane_off, ti_n);
+        if (HEAT) vload<FT, CPL, NT>(r_re + lane_off, re_n);
+        if (need_Taux) vload<FT, CPL, NT>(r_Ta + lane_off, Ta_n);
     };
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            vl_n[k][j] = ti_n[k][j] = re_n[k][j] = FT(0);
-            Ta_n[k][j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
-        }
-        if (k < n) fetch(k, k);
-    }
+    auto advance_in = [&]() {
+        r_vl += stride;
+        r_ti += stride;
+        if (HEAT) r_re += stride;
+        if (need_Taux) r_Ta += stride;
+    };
+    fetch();
 
-    // emit the result for cell `lev` given its two face fluxes
-    // (u_vl, u_ti, u_re) are the cell's own input values, kept in registers
-    auto emit = [&](int lev, const FT (&Fw_hi)[CPL], const FT (&Fe_hi)[CPL], const FT (&u_vl)[CPL],
-                    const FT (&u_ti)[CPL], const FT (&u_re)[CPL]) {
-        const int64_t o = int64_t(lev) * stride + col0;
-        FT dvl[CPL], dre[CPL], zero[CPL];
+    // emit the result of the cell the OUT/BASE row pointers address
+    auto emit = [&](const FT (&Fw_hi)[CPL], const FT (&Fe_hi)[CPL], const FT (&u_vl)[CPL],
+                    const FT (&u_re)[CPL]) {
+        FT dvl[CPL], dre[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             dvl[j] = WATER ? -((Fw_hi[j] - Fw_lo[j]) * P.inv_dz) : FT(0);
             dre[j] = HEAT ? -((Fe_hi[j] - Fe_lo[j]) * P.inv_dz) : FT(0);
-            zero[j] = FT(0);
-            if (col0 + j < P.ncols) bad = bad || !finite(dvl[j]) || !finite(dre[j]);
+            if (CPL == 1 || col0 + j < P.ncols) {
+                if (WATER) nf_acc = __builtin_fma(dvl[j], FT(0), nf_acc);
+                if (HEAT) nf_acc = __builtin_fma(dre[j], FT(0), nf_acc);
+            }
         }
         if (MODE == 0) {
             if (WATER) {
-                vstore<FT, CPL, NT>(OUT.v[0] + o, dvl);
-                vstore<FT, CPL, NT>(OUT.v[1] + o, zero); // d theta_i = 0 (:182, :359)
+                FT zero[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) zero[j] = FT(0);
+                vstore<FT, CPL, NT>(o_vl + lane_off, dvl);
+                vstore<FT, CPL, NT>(o_ti + lane_off, zero); // d theta_i = 0 (:182, :359)
             }
-            if (HEAT) vstore<FT, CPL, NT>(OUT.v[2] + o, dre);
+            if (HEAT) vstore<FT, CPL, NT>(o_re + lane_off, dre);
         } else {
-            // fused SSPRK33 stage; theta_i has a zero tendency and is carried unchanged
-            auto stage = [&](int var, const FT (&u)[CPL], const FT (&k)[CPL]) {
+            auto stage = [&](const FT* brow, FT* orow, const FT (&u)[CPL], const FT (&k)[CPL]) {
                 FT b[CPL], r[CPL];
-                if (MODE != 1) vload<FT, CPL, NT>(BASE.v[var] + o, b);
+                if (MODE != 1) vload<FT, CPL, NT>(brow + lane_off, b);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     if (MODE == 1)
@@ -177,30 +215,35 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     else
                         r[j] = (b[j] + FT(2) * u[j] + FT(2) * dt * k[j]) * FT(1.0 / 3.0);
                 }
-                vstore<FT, CPL, false>(OUT.v[var] + o, r);
+                vstore<FT, CPL, NT>(orow + lane_off, r);
             };
-            if (WATER) {
-                stage(0, u_vl, dvl);
-                stage(1, u_ti, zero);
-            }
-            if (HEAT) stage(2, u_re, dre);
+            if (WATER) stage(b_vl, o_vl, u_vl, dvl);
+            if (HEAT) stage(b_re, o_re, u_re, dre);
+        }
+        if (WATER) {
+            o_vl += stride;
+            if (MODE == 0) o_ti += stride;
+            if (MODE >= 2) b_vl += stride;
+        }
+        if (HEAT) {
+            o_re += stride;
+            if (MODE >= 2) b_re += stride;
         }
     };
 
-    for (int i0 = 0; i0 < n; i0 += PF) {
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int i = i0 + k;
-        if (PF > 1 && i >= n) break;
+    for (int i = 0; i < n; ++i) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            vl[j] = vl_n[k][j];
-            ti[j] = ti_n[k][j];
-            re[j] = re_n[k][j];
-            Ta[j] = Ta_n[k][j];
+            vl[j] = vl_n[j];
+            ti[j] = ti_n[j];
+            re[j] = re_n[j];
+            Ta[j] = Ta_n[j];
         }
-        if (i + PF < n) fetch(i + PF, k); // keep PF levels in flight ahead of the compute
-        const FT z = P.zc[i];
+        if (i + 1 < n) { // prefetch the next level while this one is computed
+            advance_in();
+            fetch();
+        }
+        const FT z = s_zc[i];
         FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -239,7 +282,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     if (WATER) Fe[j] = Fe[j] - ((E_p[j] + E[j]) * FT(0.5)) * gh;
                 }
             }
-            emit(i - 1, Fw, Fe, vl_p, ti_p, re_p);
+            emit(Fw, Fe, vl_p, re_p);
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 Fw_lo[j] = Fw[j];
@@ -249,7 +292,6 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             vl_p[j] = vl[j];
-            ti_p[j] = ti[j];
             re_p[j] = re[j];
             K_p[j] = K[j];
             h_p[j] = h[j];
@@ -258,7 +300,6 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             kap_p[j] = kap[j];
             E_p[j] = E[j];
         }
-      }
     }
     {
         FT Fw[CPL], Fe[CPL];
@@ -266,9 +307,9 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         for (int j = 0; j < CPL; ++j)
             boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
                                                    K_p[j], psi_p[j], Fe[j], Fw[j]);
-        emit(n - 1, Fw, Fe, vl_p, ti_p, re_p);
+        emit(Fw, Fe, vl_p, re_p);
     }
-    if (bad) atomicOr(P.status, 1u);
+    if (nf_acc != nf_acc) atomicOr(P.status, 1u);
 }
 
 // --------------------------------------------------------- diagnostics
@@ -472,15 +513,16 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
                             int block, hipStream_t s) {
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
+    const unsigned dyn = (unsigned)(((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15); // z_i in LDS
     if (!M::is_production) { // MathLibm: tendency only
-        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, 0, s, P, in, aux, base, out, dt);
+        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt);
         return;
     }
     switch (mode) {
-        case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, 0, s, P, in, aux, base, out, dt); break;
-        case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, 0, s, P, in, aux, base, out, dt); break;
-        case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, 0, s, P, in, aux, base, out, dt); break;
-        default: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, 0, s, P, in, aux, base, out, dt); break;
+        case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt); break;
+        case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, dyn, s, P, in, aux, base, out, dt); break;
+        case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, dyn, s, P, in, aux, base, out, dt); break;
+        default: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt); break;
     }
 }
 
@@ -501,9 +543,7 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
         launch_rhs_mode<FT, MODEL_RICHARDS, false, false, KCfg<C, F, N>, M>(P, in, aux, base, out, dt, 0, block, s); \
         return;                                                                                      \
     }
-        LH_TRY(1, 1, false) LH_TRY(1, 2, false) LH_TRY(1, 3, false) LH_TRY(1, 4, false)
-        LH_TRY(1, 1, true) LH_TRY(1, 2, true) LH_TRY(1, 4, true)
-        LH_TRY(2, 1, false) LH_TRY(2, 2, false) LH_TRY(2, 2, true) LH_TRY(2, 1, true)
+        LH_TRY(1, 1, false) LH_TRY(1, 1, true) LH_TRY(2, 1, false) LH_TRY(2, 1, true)
 #undef LH_TRY
     }
 #endif

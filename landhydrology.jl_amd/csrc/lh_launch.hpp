@@ -16,6 +16,7 @@ template <> struct DefaultCfg<float> { using type = KCfg<2, 1, false>; };
 // honour cpl/pf/nt, every build honours block)
 struct Tune {
     int block = 0, cpl = 0, pf = 0, nt = -1;
+    int pad = -1; // plane address stagger in bytes (state allocation)
 };
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)

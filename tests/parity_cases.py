@@ -431,6 +431,15 @@ def closure_tolerances(case: Case, diag, Cw: float):
         u = np.where(Se < 1, Se ** (-1.0 / m) - 1.0, 0.0)
         condpsi = np.where(Se < 1, 1.0 + (u + 1.0) / (n * np.maximum(u, 1e-300)) +
                            np.abs(np.log(np.maximum(Se, 1e-300))) / (m * n), 2.0)
+    # conductivity factors: exp(gamma (T - T_ref)) and 10^(-Omega f_i) are powers too
+    cf = om.cf
+    if cf.viscosity_kind:
+        condK = condK + np.abs(cf.gamma * (T - cf.T_ref))
+    if cf.impedance_kind:
+        with np.errstate(all="ignore"):
+            tl = np.minimum(vl, nu - ti)
+            f_i = np.where(tl + ti != 0, ti / (tl + ti), 0.0)
+        condK = condK + cf.Omega * np.abs(f_i) * np.log(10.0)
     absK = eps * np.abs(K) * np.minimum(condK, 1e12) + 1e-300
     # psi near Se -> 1 from below is O(eps^(1/n)); give it that floor
     alpha = _percol(case, "vg_alpha", om.vg.alpha)[:, None]

@@ -24,7 +24,11 @@ nlev = case.om.nlev
 bpc = bench.WORKLOADS[workload][1]
 nmodels = int(os.environ.get("NMODELS", "2"))   # separate allocations: placement effects
 models = []
+pads = os.environ.get("PADS", "").split(",") if os.environ.get("PADS") else [None] * nmodels
+nmodels = len(pads)
 for k in range(nmodels):
+    if pads[k] is not None:
+        os.environ["LH_TUNE"] = f"pad={pads[k]}"
     g = pc.GpuModel(case)
     Y, Ya = g.prognostic_and_aux()
     dY = g.state(0)
@@ -37,7 +41,7 @@ for rnd in range(3):
     for cfg in cfgs:
         for k, (g, Y, Ya, dY) in enumerate(models):
             F, L, ctx = g.F, g.L, g.ctx
-            F.check(L.lh_set_tuning(ctx, cfg.encode()), ctx)
+            F.check(L.lh_set_tuning(ctx, (cfg + (f",pad={pads[k]}" if pads[k] is not None else "")).encode()), ctx)
             for _ in range(5):
                 g.rhs(Y, Ya, dY)
             if rnd == 0 and k == 0:
@@ -51,7 +55,7 @@ for rnd in range(3):
             ms = C.c_float()
             F.check(L.lh_timer_stop(ctx, C.byref(ms)), ctx)
             res[(cfg, k)].append(ms.value / reps)
-print(f"workload {workload}: {ncols} cols x {nlev} lev, {bpc} B/cell; {nmodels} separately allocated models")
+print(f"workload {workload}: {ncols} cols x {nlev} lev, {bpc} B/cell; {nmodels} separately allocated models, pads={pads}")
 for cfg in cfgs:
     line = f"  {cfg or '(default)':28s}"
     for k in range(nmodels):
