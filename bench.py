@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-process path on a single GPU)")
     ap.add_argument("--stepper", action="store_true",
                     help="also time the fused device SSPRK33 stepper (extra JSON field)")
     return ap.parse_args()
@@ -102,18 +105,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
 
     import __graft_entry__ as g
     import parity_cases as pc
-    F = g.load_package()._ffi
+    pkg = g.load_package()
+    F = pkg._ffi
 
-    case = build_case(a.workload, a.ncols, rank * a.ncols)
+    # weak scaling: rank r owns the block [r*ncols, (r+1)*ncols) of the global ensemble
+    lo, hi = pkg.partition.block_range(world * a.ncols, rank, world)
+    case = build_case(a.workload, hi - lo, lo)
     nlev = case.om.nlev
     # one explicit HIP stream shared by torch (events, collectives' stream
     # dependencies) and the library: torch's default stream is the NULL handle,
@@ -132,7 +141,7 @@ def main():
         F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
         if world > 1 and i % 3 == 2:     # once per SSPRK33 step
             F.check(L.lh_stable_dt_device(ctx, Y, Ya, 0.5, tdt.data_ptr()), ctx)
-            dist.all_reduce(tdt, op=dist.ReduceOp.MIN)
+            pkg.partition.global_min_dt(tdt)
 
     def barrier():
         if world > 1:

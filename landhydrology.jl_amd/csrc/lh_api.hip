@@ -171,6 +171,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.Ksat = P.vg_Ksat;
     u.inv_por = FT(1) / (u.nu - u.theta_r);
     u.inv_S_s = FT(1) / u.S_s;
+    u.inv_nu = FT(1) / u.nu;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
     if (!(u.nu > u.theta_r)) u.Ksat = u.inv_S_s = u.log2_alpha = u.alpha_pnn = FT(NAN);
     {

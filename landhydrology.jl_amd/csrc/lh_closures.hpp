@@ -48,6 +48,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.theta_lim = c.theta_r + Limits<FT>::eps();
     c.inv_por = FT(1) / (c.nu - c.theta_r);
     c.inv_S_s = FT(1) / c.S_s;
+    c.inv_nu = FT(1) / c.nu;
     c.log2_alpha = MathLibm<FT>::log2(alpha);
     poison_invalid(c);
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
@@ -189,14 +190,17 @@ __device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
     const FT nu_eff = c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
     const FT tw = tl + ti;
-    const FT S_r = tw / c.nu;
+    // production: reciprocals formed once per column / by the fast rcp
+    const FT S_r = M::is_production ? tw * c.inv_nu : tw / c.nu;
     FT K_e;
     if (ti < Limits<FT>::eps()) {
         FT e = mm.exp(-P.b * S_r);
         FT a = mm.pow_neg3(FT(1) + e);          // (1 + exp(-b S_r))^(-3)
-        FT h = (FT(1) - S_r) / FT(2);
+        FT h = M::is_production ? (FT(1) - S_r) * FT(0.5) : (FT(1) - S_r) / FT(2);
         FT d = a - h * h * h;                   // ((1 - S_r)/2)^3
-        K_e = mm.pow(S_r, P.kersten_exp_unfrozen) * mm.pow(d, P.one_minus_om);
+        // (.)^(1 - nu_om): the exponent is exactly 1 for soils without organic matter
+        FT dp = (M::is_production && P.one_minus_om == FT(1)) ? d : mm.pow(d, P.one_minus_om);
+        K_e = mm.pow(S_r, P.kersten_exp_unfrozen) * dp;
     } else {
         K_e = mm.pow(S_r, P.kersten_exp_frozen);
     }
@@ -207,18 +211,21 @@ __device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
         // kappa_unf^(tl/tw) * kappa_fr^0 with tl/tw == 1 exactly
         k_sat = P.kappa_sat_unfrozen;
     } else {
-        k_sat = mm.pow(P.kappa_sat_unfrozen, tl / tw) * mm.pow(P.kappa_sat_frozen, ti / tw);
+        const FT itw = M::is_production ? mm.rcp(tw) : FT(1) / tw;
+        k_sat = mm.pow(P.kappa_sat_unfrozen, tl * itw) * mm.pow(P.kappa_sat_frozen, ti * itw);
     }
     return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
 }
 
-template <typename FT>
-__device__ __forceinline__ FT temperature_closure(const DevParams<FT>& P, const ColC<FT>& c, FT vl,
-                                                  FT ti, FT rhoe, FT& rho_c_s) {
+template <typename FT, typename M>
+__device__ __forceinline__ FT temperature_closure(const M& mm, const DevParams<FT>& P,
+                                                  const ColC<FT>& c, FT vl, FT ti, FT rhoe,
+                                                  FT& rho_c_s) {
     const FT nu_eff = c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
     rho_c_s = P.rho_c_ds + tl * P.rhocp_l + ti * P.rhocp_i;
-    return P.T_ref + (rhoe + ti * P.rho_i * P.LH_f0) / rho_c_s;
+    const FT num = rhoe + ti * P.rho_i * P.LH_f0;
+    return P.T_ref + (M::is_production ? num * mm.rcp(rho_c_s) : num / rho_c_s);
 }
 
 // boundary_fluxes for one face of one column: boundary_conditions.jl:470-489

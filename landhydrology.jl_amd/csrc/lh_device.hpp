@@ -22,7 +22,7 @@ struct ColC {
     FT alpha_pnn;                   // alpha^(-n)
     FT Ksat;
     FT k_dry;                       // SoilHeatParameterizations.jl:280-294
-    FT inv_por, inv_S_s;            // 1/(nu - theta_r), 1/S_s
+    FT inv_por, inv_S_s, inv_nu;    // 1/(nu - theta_r), 1/S_s, 1/nu
     FT log2_alpha;                  // log2(alpha), for the log-domain psi
 };
 

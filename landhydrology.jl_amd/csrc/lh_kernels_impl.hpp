@@ -40,6 +40,7 @@ template <> struct Vec<double, 2> { typedef double type __attribute__((ext_vecto
 template <> struct Vec<float, 1> { using type = float; };
 template <> struct Vec<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Vec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<double, 4> { typedef double type __attribute__((ext_vector_type(4))); };
 
 template <typename FT, int N, bool NT = false>
 __device__ __forceinline__ void vload(const FT* p, FT (&out)[N]) {
@@ -189,8 +190,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             dvl[j] = WATER ? -((Fw_hi[j] - Fw_lo[j]) * P.inv_dz) : FT(0);
             dre[j] = HEAT ? -((Fe_hi[j] - Fe_lo[j]) * P.inv_dz) : FT(0);
             if (CPL == 1 || col0 + j < P.ncols) {
-                if (WATER) nf_acc = __builtin_fma(dvl[j], FT(0), nf_acc);
-                if (HEAT) nf_acc = __builtin_fma(dre[j], FT(0), nf_acc);
+                if (WATER) nf_acc = fma_ft(dvl[j], FT(0), nf_acc);
+                if (HEAT) nf_acc = fma_ft(dre[j], FT(0), nf_acc);
             }
         }
         if (MODE == 0) {
@@ -252,7 +253,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             K[j] = psi[j] = h[j] = E[j] = FT(0);
             if (HEAT) {
                 FT rcs;
-                T[j] = temperature_closure<FT>(P, c[j], vl[j], ti[j], re[j], rcs);
+                T[j] = temperature_closure<FT, M>(mm, P, c[j], vl[j], ti[j], re[j], rcs);
                 kap[j] = kappa_closure<FT, M>(mm, P, c[j], vl[j], ti[j]);
             }
             if (WATER) {
@@ -333,7 +334,7 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
         FT T = need_Taux ? AUX.v[3][o + col] : FT(288), kap = FT(0), K = FT(0), psi = FT(0);
         if (HEAT) {
             FT rcs;
-            T = temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
+            T = temperature_closure<FT, M>(mm, P, c, vl, ti, IN.v[2][o + col], rcs);
             kap = kappa_closure<FT, M>(mm, P, c, vl, ti);
         }
         if (WATER) water_closures<FT, M, FACTORS>(mm, P, c, vl, ti, T, K, psi);
@@ -376,7 +377,7 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
             FT K = FT(0), dpsi = FT(0), kap = FT(0), rcs = FT(1);
             FT Tc = FT(288);
             if (MODEL == MODEL_RICHARDS && P.viscosity_kind) Tc = AUX.v[3][o + col];
-            if (HEAT) Tc = temperature_closure<FT>(P, c, vl, ti, IN.v[2][o + col], rcs);
+            if (HEAT) Tc = temperature_closure<FT, M>(mm, P, c, vl, ti, IN.v[2][o + col], rcs);
             if (WATER) {
                 FT psi;
                 water_closures<FT, M, true>(mm, P, c, vl, ti, Tc, K, psi);
@@ -533,17 +534,16 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     using CFG = typename DefaultCfg<FT>::type;
     const int block = tune.block > 0 ? tune.block : 256;
 #ifdef LH_TUNING_VARIANTS
-    // tuning builds: alternative launch shapes for the plain Richards tendency
-    if (MODEL == MODEL_RICHARDS && !factors && !percol && mode == 0 && M::is_production &&
-        (tune.cpl > 0 || tune.pf > 0 || tune.nt >= 0)) {
-        const int cpl = tune.cpl > 0 ? tune.cpl : CFG::CPL, pf = tune.pf > 0 ? tune.pf : CFG::PF;
-        const bool nt = tune.nt >= 0 ? tune.nt != 0 : CFG::NT;
-#define LH_TRY(C, F, N)                                                                              \
-    if (cpl == C && pf == F && nt == N) {                                                            \
-        launch_rhs_mode<FT, MODEL_RICHARDS, false, false, KCfg<C, F, N>, M>(P, in, aux, base, out, dt, 0, block, s); \
-        return;                                                                                      \
+    // tuning builds: alternative columns-per-lane for the plain tendency kernels
+    if (!factors && !percol && mode == 0 && M::is_production && tune.cpl > 0) {
+        const bool ntv = tune.nt >= 0 ? tune.nt != 0 : true;
+#define LH_TRY(C, N)                                                                               \
+    if (tune.cpl == C && ntv == N) {                                                               \
+        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, 1, N>, M>(P, in, aux, base, out, dt, 0, block, s); \
+        return;                                                                                    \
     }
-        LH_TRY(1, 1, false) LH_TRY(1, 1, true) LH_TRY(2, 1, false) LH_TRY(2, 1, true)
+        LH_TRY(1, false) LH_TRY(1, true) LH_TRY(2, false) LH_TRY(2, true)
+        if (sizeof(FT) == 4) { LH_TRY(4, true) }
 #undef LH_TRY
     }
 #endif
