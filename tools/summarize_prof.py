@@ -34,9 +34,9 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_grbm"):
     for k, v in sorted(acc.items()):
         print(f"  {k}: mean/launch={sum(v)/len(v):.6g} (n={len(v)})")
         if k == "FETCH_SIZE":
-            print(f"    -> HBM read bytes/launch (x2 gfx950 correction, KiB): {2*1024*sum(v)/len(v):.6g}")
+            print(f"    -> HBM read bytes/launch (bytes; FETCH_SIZE KiB x 1024 x 2, the gfx950 wide-read correction): {2*1024*sum(v)/len(v):.6g}")
         if k == "WRITE_SIZE":
-            print(f"    -> HBM write bytes/launch (KiB): {1024*sum(v)/len(v):.6g}")
+            print(f"    -> HBM write bytes/launch (bytes; WRITE_SIZE KiB x 1024): {1024*sum(v)/len(v):.6g}")
 for f in glob.glob(os.path.join(d, "bench_trace.log")):
     for line in open(f):
         if line.startswith("{"):
