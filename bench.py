@@ -178,6 +178,17 @@ def main():
 
     cells = a.ncols * nlev
     bytes_per_cell = WORKLOADS[a.workload][1]
+    # HBM bytes per launch from the PMC passes of this same command (rocprofv3
+    # cannot run inside the timed process): profiles/pmc_traffic.json, written by
+    # tools/gpu_profile.sh + tools/summarize_prof.py; null when sizes differ
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            tr = json.load(fh).get(a.workload)
+        if tr and tr["ncols"] == a.ncols and tr["nlev"] == nlev:
+            traffic = tr["total_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
     value = world * cells * a.steps / wall
     achieved = cells * bytes_per_cell / (kern_ms * 1e-3) / 1e9
     out = {
@@ -200,8 +211,9 @@ def main():
                    "partition": f"block over {world} rank(s); stable-dt RCCL min all-reduce every 3rd eval"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel_ms": kern_ms, "bytes_per_cell": bytes_per_cell},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kern_ms, "bytes_per_cell": bytes_per_cell,
+                     "algorithmic_bytes_per_launch": cells * bytes_per_cell},
     }
     if a.stepper:
         F.check(L.lh_step_ssprk33(ctx, Y, Ya, 0.0, 1e-3, 2, None), ctx)
