@@ -212,8 +212,16 @@ int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out
 int lh_step_ssprk33(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double dt,
                     int64_t nsteps, const double* bc_stage_values);
 
+/* One SSPRK33 step whose dt is read from DEVICE memory (one FT value, e.g. the
+ * output of lh_stable_dt_device after an RCCL min all-reduce): adaptive stepping
+ * across ranks without a host round trip.  bc_stage_values: NULL or [3][2][2]. */
+int lh_step_ssprk33_device_dt(lh_ctx*, lh_state* Y, const lh_state* Ya, double t,
+                              const void* dt_device_ft, const double* bc_stage_values);
+
 /* Build-defined stable step (the reference uses a fixed user dt):
- * min over owned cells of courant*dz^2/max(K dpsi/dvl, kappa/rho_c_s).
+ * courant*dz^2 / max over owned faces of the face diffusivities
+ * ((K_lo+K_hi)/2 * max dpsi/dvl, (kappa_lo+kappa_hi)/2 / min rho_c_s; boundary
+ * cells and Dirichlet faces with their own coefficients).
  * _device leaves the FT result in device memory (for an RCCL min all-reduce
  * across ranks without a host round trip); the host form synchronises. */
 int lh_stable_dt(lh_ctx*, const lh_state* Y, const lh_state* Ya, double courant,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "lh_rhs": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "lh_diagnostics": (C.c_int, [_P, _P, _P, _P]),
     "lh_step_ssprk33": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, _DP]),
+    "lh_step_ssprk33_device_dt": (C.c_int, [_P, _P, _P, C.c_double, _P, _DP]),
     "lh_stable_dt": (C.c_int, [_P, _P, _P, C.c_double, _DP]),
     "lh_stable_dt_device": (C.c_int, [_P, _P, _P, C.c_double, _P]),
     "lh_get_status": (C.c_int, [_P, C.POINTER(C.c_uint32)]),

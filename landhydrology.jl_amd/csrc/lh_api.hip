@@ -275,14 +275,14 @@ Planes<FT> planes_of(const lh_state* s) {
 
 template <typename FT>
 int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
-           double dt, int mode, const double* bc_override) {
+           double dt, int mode, const double* bc_override, const void* dt_device = nullptr) {
     DevParams<FT> P = make_params<FT>(c);
     if (bc_override)
         for (int f = 0; f < 2; ++f)
             for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
     launch_rhs<FT>(P, planes_of<FT>(in), planes_of<FT>(aux), planes_of<FT>(base), planes_of<FT>(out),
-                   FT(dt), mode, factors, any_percol(c), c->math, c->tune, c->stream);
+                   FT(dt), static_cast<const FT*>(dt_device), mode, factors, any_percol(c), c->math, c->tune, c->stream);
     LH_HIP(c, hipGetLastError());
     return LH_OK;
 }
@@ -705,6 +705,29 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
                                         : do_rhs<float>(c, in, Ya, Y, out, dt, stage + 1, ov);
             if (rc) return rc;
         }
+    }
+    return LH_OK;
+}
+
+int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t,
+                              const void* dt_device_ft, const double* bcv) {
+    (void)t;
+    if (!c || !dt_device_ft) return fail(c, LH_EINVAL, "lh_step_ssprk33_device_dt: NULL argument");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    if (!c->scratch_u1 && (rc = state_alloc(c, pm, &c->scratch_u1))) return rc;
+    lh_state* U1 = c->scratch_u1;
+    for (int stage = 0; stage < 3; ++stage) {
+        const double* ov = bcv ? bcv + stage * 4 : nullptr;
+        const lh_state* in = stage == 0 ? Y : U1;
+        lh_state* out = stage == 2 ? Y : U1;
+        rc = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, 0.0, stage + 1, ov, dt_device_ft)
+                                    : do_rhs<float>(c, in, Ya, Y, out, 0.0, stage + 1, ov, dt_device_ft);
+        if (rc) return rc;
     }
     return LH_OK;
 }

@@ -113,7 +113,10 @@ __device__ __forceinline__ bool finite(FT x) {
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE>
 __global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
-           const Planes<FT> OUT, const FT dt) {
+           const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
+    // the step size either comes by value or is read from device memory, where a
+    // preceding stable-dt reduction / RCCL min all-reduce left it (no host sync)
+    const FT dt = (MODE != 0 && dt_device) ? *dt_device : dt_value;
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     constexpr int CPL = CFG::CPL;
@@ -510,27 +513,27 @@ static inline dim3 grid_for(int64_t work, int block) {
 
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M>
 static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
-                            const Planes<FT>& base, const Planes<FT>& out, FT dt, int mode,
-                            int block, hipStream_t s) {
+                            const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
+                            int mode, int block, hipStream_t s) {
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
     const unsigned dyn = (unsigned)(((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15); // z_i in LDS
     if (!M::is_production) { // MathLibm: tendency only
-        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt);
+        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
         return;
     }
     switch (mode) {
-        case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt); break;
-        case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, dyn, s, P, in, aux, base, out, dt); break;
-        case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, dyn, s, P, in, aux, base, out, dt); break;
-        default: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt); break;
+        case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+        case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+        case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+        default: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
     }
 }
 
 template <typename FT, int MODEL, typename M>
 static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
-                             const Planes<FT>& base, const Planes<FT>& out, FT dt, int mode,
-                             bool factors, bool percol, const Tune& tune, hipStream_t s) {
+                             const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
+                             int mode, bool factors, bool percol, const Tune& tune, hipStream_t s) {
     using CFG = typename DefaultCfg<FT>::type;
     const int block = tune.block > 0 ? tune.block : 256;
 #ifdef LH_TUNING_VARIANTS
@@ -539,7 +542,7 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
         const bool ntv = tune.nt >= 0 ? tune.nt != 0 : true;
 #define LH_TRY(C, N)                                                                               \
     if (tune.cpl == C && ntv == N) {                                                               \
-        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, 1, N>, M>(P, in, aux, base, out, dt, 0, block, s); \
+        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, 1, N>, M>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
         return;                                                                                    \
     }
         LH_TRY(1, false) LH_TRY(1, true) LH_TRY(2, false) LH_TRY(2, true)
@@ -557,8 +560,8 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     using CFGP = KCfg<CFG::CPL, CFG::PF, false>;
 #define LH_GO(F, PC)                                                                                  \
     do {                                                                                              \
-        if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M>(P, in, aux, base, out, dt, mode, block, s); \
-        else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M>(P, in, aux, base, out, dt, mode, block, s);   \
+        if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+        else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s);   \
     } while (0)
     if (factors) {
         if (percol) LH_GO(true, true);
@@ -572,13 +575,13 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
 
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
-                const Planes<FT>& base, const Planes<FT>& out, FT dt, int mode, bool factors,
-                bool percol, int math, const Tune& tune, hipStream_t s) {
+                const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
+                bool factors, bool percol, int math, const Tune& tune, hipStream_t s) {
 #define LH_DISPATCH_MODEL(MATH)                                                                 \
     switch (P.model) {                                                                          \
-        case MODEL_RICHARDS: launch_rhs_model<FT, MODEL_RICHARDS, MATH>(P, in, aux, base, out, dt, mode, factors, percol, tune, s); break; \
-        case MODEL_HEAT: launch_rhs_model<FT, MODEL_HEAT, MATH>(P, in, aux, base, out, dt, mode, factors, percol, tune, s); break;         \
-        default: launch_rhs_model<FT, MODEL_COUPLED, MATH>(P, in, aux, base, out, dt, mode, factors, percol, tune, s); break;              \
+        case MODEL_RICHARDS: launch_rhs_model<FT, MODEL_RICHARDS, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break; \
+        case MODEL_HEAT: launch_rhs_model<FT, MODEL_HEAT, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break;         \
+        default: launch_rhs_model<FT, MODEL_COUPLED, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break;              \
     }
     // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
     // the fused SSPRK33 stages always run the production math.
@@ -660,8 +663,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
 // explicit instantiation for one working type per translation unit
 #define LH_INSTANTIATE(FT)                                                                            \
     template void launch_rhs<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,          \
-                                 const Planes<FT>&, const Planes<FT>&, FT, int, bool, bool, int,      \
-                                 const Tune&, hipStream_t);                                                      \
+                                 const Planes<FT>&, const Planes<FT>&, FT, const FT*, int, bool, bool, \
+                                 int, const Tune&, hipStream_t);                                                      \
     template void launch_diag<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,         \
                                   const Planes<FT>&, bool, int, hipStream_t);                         \
     template void launch_stable_dt<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,    \

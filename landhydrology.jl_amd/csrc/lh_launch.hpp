@@ -22,8 +22,8 @@ struct Tune {
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
-                const Planes<FT>& base, const Planes<FT>& out, FT dt, int mode, bool factors,
-                bool percol, int math, const Tune& tune, hipStream_t s);
+                const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
+                bool factors, bool percol, int math, const Tune& tune, hipStream_t s);
 template <typename FT>
 void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                  const Planes<FT>& out, bool percol, int math, hipStream_t s);

@@ -656,6 +656,18 @@ def make_rhs(model: SoilModel):
     return rhs
 
 
+def stable_dt(model: SoilModel, Y: "FieldVector", Ya=None, courant: float = 0.5) -> float:
+    """Build extension (the reference steps with a fixed user dt): the largest
+    step the explicit diffusive bound allows on this rank's columns,
+    courant * dz^2 / max face diffusivity (lh_stable_dt).  Across ranks take the
+    minimum with `partition.global_min_dt`."""
+    be = model._backend()
+    out = C.c_double()
+    ya = Ya.handle if isinstance(Ya, FieldVector) else None
+    F.check(F.lib().lh_stable_dt(be.ctx, Y.handle, ya, float(courant), C.byref(out)), be.ctx)
+    return out.value
+
+
 # --------------------------------------------------------------- Simulations
 
 

@@ -294,3 +294,48 @@ def test_full_size_properties(workload):
         rel = np.abs(vl1.sum(axis=1) - m0) / m0
         assert np.max(rel) < (1e-13 if case.dtype == np.float64 else 2e-6)
         assert np.max(np.abs(vl1 - case.vl)) > 0          # it moved
+
+
+def test_stable_dt_matches_oracle_and_device_dt_stepping():
+    """lh_stable_dt against the oracle's rule, and adaptive stepping with dt kept in
+    device memory (lh_stable_dt_device -> [RCCL min all-reduce] ->
+    lh_step_ssprk33_device_dt) against stepping with the same dt passed by value."""
+    import torch
+    for name in ("c2_richards_f64", "c3_coupled_f32", "mixed_smooth_f64", "c1_dirichlet_f64",
+                 "c5_percol_f64", "heat_dirichlet_f64", "richards_viscosity_f64"):
+        case = pc.make_case(name, ncols=None if name != "c1_dirichlet_f64" else 5)
+        want = O.stable_dt(case.om, case.vl, case.ti, case.rhoe, 0.5, case.T_aux)
+        with pc.GpuModel(case) as g:
+            F = g.F
+            Y, Ya = g.prognostic_and_aux()
+            dt = C.c_double()
+            F.check(g.L.lh_stable_dt(g.ctx, Y, Ya, 0.5, C.byref(dt)), g.ctx)
+            rel = 1e-11 if case.dtype == np.float64 else 1e-4
+            assert abs(dt.value - want) <= rel * want, (name, dt.value, want)
+            if name not in ("c2_richards_f64", "c3_coupled_f32"):
+                continue
+            # adaptive loop, dt never leaves the device
+            tdt = torch.zeros(1, device="cuda",
+                              dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
+            dts = []
+            for _ in range(5):
+                F.check(g.L.lh_stable_dt_device(g.ctx, Y, Ya, 0.2, tdt.data_ptr()), g.ctx)
+                _pkg().partition.global_min_dt(tdt)          # no-op without a process group
+                F.check(g.L.lh_step_ssprk33_device_dt(g.ctx, Y, Ya, 0.0, tdt.data_ptr(), None), g.ctx)
+                F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+                dts.append(float(tdt.item()))
+            var = F.LH_VAR_VARTHETA_L
+            a = g.download(Y, var)
+        # same sequence of dt values passed from the host
+        with pc.GpuModel(case) as g2:
+            Y2, Ya2 = g2.prognostic_and_aux()
+            for d in dts:
+                g2.F.check(g2.L.lh_step_ssprk33(g2.ctx, Y2, Ya2, 0.0, d, 1, None), g2.ctx)
+            b = g2.download(Y2, var)
+        assert np.array_equal(a, b), name
+        assert all(d > 0 and math.isfinite(d) for d in dts)
+
+
+def _pkg():
+    import __graft_entry__ as ge
+    return ge.load_package()
