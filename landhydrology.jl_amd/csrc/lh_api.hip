@@ -173,7 +173,15 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_S_s = FT(1) / u.S_s;
     u.inv_nu = FT(1) / u.nu;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
-    if (!(u.nu > u.theta_r)) u.Ksat = u.inv_S_s = u.log2_alpha = u.alpha_pnn = FT(NAN);
+    {   // exponent multipliers in the exp2 unit of the production math (lh_fastmath.hpp)
+        const FT sc = sizeof(FT) == 8 ? FT(128) : FT(1);
+        u.e_one = sc;
+        u.e_inv_m = sc * u.inv_m;
+        u.e_m = sc * u.m;
+        u.e_inv_n = u.inv_n;
+        u.e_log2_alpha = sc * u.log2_alpha;
+    }
+    if (!(u.nu > u.theta_r)) u.Ksat = u.inv_S_s = u.log2_alpha = u.e_log2_alpha = u.alpha_pnn = FT(NAN);
     {
         FT rho_b = (FT(1) - u.nu) * P.rho_p;
         FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;

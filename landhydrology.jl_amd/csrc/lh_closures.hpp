@@ -11,6 +11,16 @@
 
 namespace lh {
 
+// exponent multipliers in the exp2 unit of the math policy (see ColC)
+template <typename FT>
+__host__ __device__ inline void set_scaled_exponents(ColC<FT>& c, FT scale) {
+    c.e_one = scale;
+    c.e_inv_m = scale * c.inv_m;
+    c.e_m = scale * c.m;
+    c.e_inv_n = c.inv_n; // applied to an already scaled difference
+    c.e_log2_alpha = scale * c.log2_alpha;
+}
+
 // A non-positive saturation (nu <= theta_r) makes `^` raise DomainError in the
 // reference; here the column's K and psi become NaN (and the status flag is set)
 template <typename FT>
@@ -19,6 +29,7 @@ __host__ __device__ inline void poison_invalid(ColC<FT>& c) {
         c.Ksat = FT(NAN);
         c.inv_S_s = FT(NAN);
         c.log2_alpha = FT(NAN);
+        c.e_log2_alpha = FT(NAN);
         c.alpha_pnn = FT(NAN);
     }
 }
@@ -50,6 +61,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.inv_S_s = FT(1) / c.S_s;
     c.inv_nu = FT(1) / c.nu;
     c.log2_alpha = MathLibm<FT>::log2(alpha);
+    set_scaled_exponents(c, FT(M::EXP2_SCALE));
     poison_invalid(c);
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
     FT rho_b = (FT(1) - c.nu) * P.rho_p;
@@ -128,21 +140,30 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     const FT num = vls - c.theta_r;
     const FT S = num * c.inv_por;
     const bool same = (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
-    FT Se = S;
-    if (__any(!same)) { // wave-uniform skip of the reciprocal when no lane has ice
-        if (!same) Se = num * mm.rcp(nu_eff - c.theta_r);
-    }
 
-    FT Kr = FT(1), a = FT(0), Lw = FT(0);
+    // exponents are formed in the exp2 unit of the policy (c.e_* carry the scale)
     if (S < FT(1)) {
         const FT L = mm.log2(S);
-        a = L * c.inv_m;               // log2 S^(1/m)
-        const FT w = FT(1) - mm.exp2(a);
-        Lw = mm.log2(w);
-        const FT inner = FT(1) - mm.exp2(c.m * Lw);
-        Kr = mm.sqrt(S) * (inner * inner);
+        const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
+        const FT w = FT(1) - mm.exp2_scaled(a);
+        const FT Lw = mm.log2(w);
+        const FT inner = FT(1) - mm.exp2_scaled(c.e_m * Lw);
+        K = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
+        if (WANT_PSI && same) psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
+    } else {
+        K = c.Ksat; // K_r = 1
+        if (WANT_PSI && same) psi = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
     }
-    K = Kr * c.Ksat;
+    if (WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
+        const FT Se = num * mm.rcp(nu_eff - c.theta_r);
+        if (Se < FT(1)) {
+            const FT ae = mm.log2(Se) * c.e_inv_m;
+            const FT Lwe = mm.log2(FT(1) - mm.exp2_scaled(ae));
+            psi = -mm.exp2_scaled(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
+        } else {
+            psi = (Se == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+        }
+    }
     if (FACTORS) {
         FT visc = FT(1), imp = FT(1);
         if (P.viscosity_kind) visc = mm.exp(P.gamma * (T - P.T_ref_visc));
@@ -153,21 +174,6 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             imp = mm.exp2((-P.Omega * f_i) * FT(3.3219280948873623));
         }
         K = K * visc * imp;
-    }
-    if (WANT_PSI) {
-        if (Se < FT(1)) {
-            FT ae = a, Lwe = Lw;
-            if (!(same && S < FT(1))) {
-                const FT Le = mm.log2(Se);
-                ae = Le * c.inv_m;
-                Lwe = mm.log2(FT(1) - mm.exp2(ae));
-            }
-            psi = -mm.exp2((Lwe - ae) * c.inv_n - c.log2_alpha);
-        } else if (Se == FT(1)) {
-            psi = -FT(0); // -((1 - 1) alpha^-n)^(1/n)
-        } else {
-            psi = (vl - nu_eff) * c.inv_S_s;
-        }
     }
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }

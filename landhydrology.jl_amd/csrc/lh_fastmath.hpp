@@ -48,8 +48,10 @@ template <> struct MathLibm<double> {
     __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
     __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static constexpr double EXP2_SCALE = 1.0;
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
     static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    static __device__ __forceinline__ double exp2_scaled(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -61,8 +63,10 @@ template <> struct MathLibm<float> {
     __device__ __forceinline__ explicit MathLibm(const MathTables&) {}
     __device__ __forceinline__ MathLibm() {}
     static __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
+    static constexpr float EXP2_SCALE = 1.0f;
     static __device__ __forceinline__ float log2(float x) { return ::log2f(x); }
     static __device__ __forceinline__ float exp2(float x) { return ::exp2f(x); }
+    static __device__ __forceinline__ float exp2_scaled(float x) { return ::exp2f(x); }
     static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
@@ -75,48 +79,69 @@ template <typename FT> struct MathFast;
 // (Horner steps stay plain __builtin_fma: forcing the coefficients into SGPRs with
 // inline asm removes the v_mov_b64 copies hipcc makes, but it pads every asm
 // statement with s_nop hazards -- 28 per cell against 8 saved moves.)
+// A constant the compiler must keep in a VGPR pair for the kernel's lifetime
+// instead of re-materialising it with v_mov_b64 (as costly as an FMA on gfx950)
+// in front of every use: the empty asm makes its value opaque.
+__device__ __forceinline__ double vgpr_resident(double k) {
+    asm volatile("" : "+v"(k));
+    return k;
+}
+
 template <> struct MathFast<double> {
     static constexpr bool uses_tables = true;
     static constexpr bool is_production = true;
+    // exponents are handed to exp2 in units of 1/128 (x128): the argument reduction
+    // is then three additions, with no multiply by 128 and no v_mov/v_fmac pairs
+    static constexpr double EXP2_SCALE = 128.0;
     MathTables tb;
-    __device__ __forceinline__ explicit MathFast(const MathTables& t) : tb(t) {}
+    // second-highest polynomial coefficients and the rounding shifter, VGPR-resident:
+    // the first Horner step needs two constants and only one may come from SGPRs
+    double c5v, q4v, shiftv;
+    __device__ __forceinline__ explicit MathFast(const MathTables& t)
+        : tb(t), c5v(vgpr_resident(0.28853900817779268)),
+          q4v(vgpr_resident(9.6181291076284772e-3 / (128.0 * 128.0 * 128.0 * 128.0))),
+          shiftv(vgpr_resident(6755399441055744.0)) {}
 
     // log2 of a positive, finite, normal x
     __device__ __forceinline__ double log2_core(double x) const {
         const double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
         const int e = __builtin_amdgcn_frexp_exp(x);     // x = m 2^e
         const unsigned hi = (unsigned)__double2hiint(m);
-        const int i = (hi >> 12) & (LOG_TAB_N - 1);      // top 8 fraction bits
-        const double invc = tb.log_tab[2 * i];
-        const double l2c = tb.log_tab[2 * i + 1];
+        const unsigned off = (hi >> 8) & ((LOG_TAB_N - 1) << 4); // byte offset of entry (top 8 fraction bits)
+        const double* ent = reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.log_tab) + off);
+        const double invc = ent[0];
+        const double l2c = ent[1];
         const double r = __builtin_fma(m, invc, -1.0);   // |r| < 2^-8
         // log2(1 + r) = r (c1 + r (c2 + ... r c6)),  c_k = (-1)^(k+1) / (k ln 2)
-        double p = -0.24044917348149393;                 // c6 = -1/(6 ln2)
-        p = __builtin_fma(p, r, 0.28853900817779268);           // c5
-        p = __builtin_fma(p, r, -0.36067376022224085);          // c4
-        p = __builtin_fma(p, r, 0.48089834696298783);           // c3
-        p = __builtin_fma(p, r, -0.72134752044448170);          // c2
-        p = __builtin_fma(p, r, 1.4426950408889634);            // c1 = 1/ln2
+        double p = __builtin_fma(r, -0.24044917348149393, c5v); // c6 r + c5
+        p = __builtin_fma(p, r, -0.36067376022224085);   // c4
+        p = __builtin_fma(p, r, 0.48089834696298783);    // c3
+        p = __builtin_fma(p, r, -0.72134752044448170);   // c2
+        p = __builtin_fma(p, r, 1.4426950408889634);     // c1 = 1/ln2
         return __builtin_fma(r, p, (double)e + l2c);
     }
 
-    // 2^t for finite t (huge |t| saturates to 0 / inf: v_cvt_i32 saturates and
-    // v_ldexp does the rest); NaN in, NaN out
-    __device__ __forceinline__ double exp2_core(double t) const {
-        const double kd = __builtin_rint(t * (double)EXP_TAB_N);
-        const double r = __builtin_fma(kd, -1.0 / EXP_TAB_N, t); // exact, |r| <= 2^-8
-        const int k = (int)kd;
-        const double tj = tb.exp_tab[k & (EXP_TAB_N - 1)];
+    // 2^(u/128) for |u| < 2^50 (v_ldexp saturates to 0 / inf far inside that; the
+    // closures' exponents are bounded by ~53 n/(n-1)); NaN in, NaN out.
+    // k = rint(u) by the shifter trick (the low word of u + 1.5*2^52 is k), u - k in
+    // [-1/2, 1/2], 2^(j/128) from LDS, degree-5 polynomial in (u - k) with the 1/128^k
+    // folded into the coefficients.
+    __device__ __forceinline__ double exp2_scaled(double u) const {
+        const double sh = u + shiftv;
+        const int k = __double2loint(sh);
+        const double r = u - (sh - shiftv);                      // exact
+        const unsigned off = ((unsigned)k << 3) & ((EXP_TAB_N - 1) << 3);
+        const double tj = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
         const int e = k >> 7;
-        // 2^r - 1 = r (q1 + r (q2 + ... r q5)),  q_k = ln2^k / k!
-        double p = 1.3333558146428443e-3;                     // q5
-        p = __builtin_fma(p, r, 9.6181291076284772e-3);              // q4
-        p = __builtin_fma(p, r, 5.5504108664821580e-2);              // q3
-        p = __builtin_fma(p, r, 2.4022650695910071e-1);              // q2
-        p = __builtin_fma(p, r, 6.9314718055994531e-1);              // q1 = ln2
+        // 2^(r/128) - 1 = r (q1' + r (q2' + ... r q5')),  q_k' = (ln2/128)^k / k!
+        double p = __builtin_fma(r, 1.3333558146428443e-3 / (128.0 * 128.0 * 128.0 * 128.0 * 128.0), q4v);
+        p = __builtin_fma(p, r, 5.5504108664821580e-2 / (128.0 * 128.0 * 128.0)); // q3'
+        p = __builtin_fma(p, r, 2.4022650695910071e-1 / (128.0 * 128.0));         // q2'
+        p = __builtin_fma(p, r, 6.9314718055994531e-1 / 128.0);                   // q1'
         const double res = __builtin_fma(tj, r * p, tj);
         return __builtin_amdgcn_ldexp(res, e);
     }
+    __device__ __forceinline__ double exp2_core(double t) const { return exp2_scaled(t * 128.0); }
 
     // x^y with libm's results for the special bases the closures can produce:
     // x == 0 (0 or inf by the sign of y), x < 0 or NaN (NaN; the reference raises
@@ -134,7 +159,7 @@ template <> struct MathFast<double> {
         return res;
     }
     __device__ __forceinline__ double exp(double x) const {
-        double res = exp2_core(x * 1.4426950408889634);
+        double res = exp2_scaled(x * (1.4426950408889634 * 128.0));
         return (x != x) ? x : res;
     }
     // sqrt of a positive normal x: v_rsq_f64 seed, one coupled Newton step and a
@@ -176,8 +201,10 @@ template <> struct MathFast<float> {
         if (x == 1.0f || y == 0.0f) res = 1.0f; // keep 1^y and x^0 exact
         return res;
     }
+    static constexpr float EXP2_SCALE = 1.0f;
     static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
     static __device__ __forceinline__ float exp2(float t) { return __builtin_amdgcn_exp2f(t); }
+    static __device__ __forceinline__ float exp2_scaled(float t) { return __builtin_amdgcn_exp2f(t); }
     static __device__ __forceinline__ float exp(float x) {
         return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
     }
