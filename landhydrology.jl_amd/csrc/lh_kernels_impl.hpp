@@ -23,10 +23,10 @@ namespace lh {
 // The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
 // per-column / conductivity-factor variants and the libm debug policy keep what
 // they need (a bound there only produces scratch spills).
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF>
 constexpr int rhs_waves_per_simd() {
     if (!M::is_production || FACTORS || PERCOL) return 1;
-    if (MODEL == MODEL_RICHARDS) return LH_RHS_WAVES_PER_SIMD;
+    if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
 }
@@ -111,7 +111,7 @@ __device__ __forceinline__ bool finite(FT x) {
 // as a global load it would sit in the vector-memory queue behind the next
 // level's prefetch and force a full vmcnt(0) drain every level.
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE>
-__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M>()))
+__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     // the step size either comes by value or is read from device memory, where a
@@ -119,7 +119,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     const FT dt = (MODE != 0 && dt_device) ? *dt_device : dt_value;
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
-    constexpr int CPL = CFG::CPL;
+    constexpr int CPL = CFG::CPL, PF = CFG::PF;
     constexpr bool NT = CFG::NT;
     __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -156,7 +156,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     }
 
     FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
-    FT vl_n[CPL], ti_n[CPL], re_n[CPL], Ta_n[CPL]; // next level, in flight
+    FT vl_n[PF][CPL], ti_n[PF][CPL], re_n[PF][CPL], Ta_n[PF][CPL]; // PF levels in flight
     FT vl_p[CPL], re_p[CPL];                       // previous cell inputs (fused stages)
     FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
@@ -167,22 +167,29 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         K_p[j] = h_p[j] = psi_p[j] = T_p[j] = kap_p[j] = E_p[j] = Fw_lo[j] = Fe_lo[j] = FT(0);
         vl_p[j] = re_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
-        re_n[j] = FT(0);
-        Ta[j] = Ta_n[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
+        Ta[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
     }
-    auto fetch = [&]() { // loads the level the row pointers currently address
-        vload<FT, CPL, NT>(r_vl + lane_off, vl_n);
-        vload<FT, CPL, NT>(r_ti + lane_off, ti_n);
-        if (HEAT) vload<FT, CPL, NT>(r_re + lane_off, re_n);
-        if (need_Taux) vload<FT, CPL, NT>(r_Ta + lane_off, Ta_n);
-    };
-    auto advance_in = [&]() {
+    // loads the level the row pointers currently address into ring slot `slot`,
+    // then moves the pointers one level up
+    auto fetch = [&](int slot) {
+        vload<FT, CPL, NT>(r_vl + lane_off, vl_n[slot]);
+        vload<FT, CPL, NT>(r_ti + lane_off, ti_n[slot]);
+        if (HEAT) vload<FT, CPL, NT>(r_re + lane_off, re_n[slot]);
+        if (need_Taux) vload<FT, CPL, NT>(r_Ta + lane_off, Ta_n[slot]);
         r_vl += stride;
         r_ti += stride;
         if (HEAT) r_re += stride;
         if (need_Taux) r_Ta += stride;
     };
-    fetch();
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            vl_n[k][j] = ti_n[k][j] = re_n[k][j] = FT(0);
+            Ta_n[k][j] = FT(288);
+        }
+        if (k < n) fetch(k);
+    }
 
     // emit the result of the cell the OUT/BASE row pointers address
     auto emit = [&](const FT (&Fw_hi)[CPL], const FT (&Fe_hi)[CPL], const FT (&u_vl)[CPL],
@@ -235,18 +242,19 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
     };
 
-    for (int i = 0; i < n; ++i) {
+    for (int i0 = 0; i0 < n; i0 += PF) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int i = i0 + k;
+        if (PF > 1 && i >= n) break;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            vl[j] = vl_n[j];
-            ti[j] = ti_n[j];
-            re[j] = re_n[j];
-            Ta[j] = Ta_n[j];
+            vl[j] = vl_n[k][j];
+            ti[j] = ti_n[k][j];
+            re[j] = re_n[k][j];
+            Ta[j] = Ta_n[k][j];
         }
-        if (i + 1 < n) { // prefetch the next level while this one is computed
-            advance_in();
-            fetch();
-        }
+        if (i + PF < n) fetch(k); // keep PF levels in flight ahead of the one computed
         const FT z = s_zc[i];
         FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL];
 #pragma unroll
@@ -304,6 +312,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             kap_p[j] = kap[j];
             E_p[j] = E[j];
         }
+      }
     }
     {
         FT Fw[CPL], Fe[CPL];
@@ -537,16 +546,17 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     using CFG = typename DefaultCfg<FT>::type;
     const int block = tune.block > 0 ? tune.block : 256;
 #ifdef LH_TUNING_VARIANTS
-    // tuning builds: alternative columns-per-lane for the plain tendency kernels
-    if (!factors && !percol && mode == 0 && M::is_production && tune.cpl > 0) {
+    // tuning builds: alternative columns-per-lane / prefetch depth for the plain tendency kernels
+    if (!factors && !percol && mode == 0 && M::is_production && (tune.cpl > 0 || tune.pf > 0)) {
         const bool ntv = tune.nt >= 0 ? tune.nt != 0 : true;
-#define LH_TRY(C, N)                                                                               \
-    if (tune.cpl == C && ntv == N) {                                                               \
-        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, 1, N>, M>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
+        const int cplv = tune.cpl > 0 ? tune.cpl : CFG::CPL, pfv = tune.pf > 0 ? tune.pf : CFG::PF;
+#define LH_TRY(C, F, N)                                                                            \
+    if (cplv == C && pfv == F && ntv == N) {                                                       \
+        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
         return;                                                                                    \
     }
-        LH_TRY(1, false) LH_TRY(1, true) LH_TRY(2, false) LH_TRY(2, true)
-        if (sizeof(FT) == 4) { LH_TRY(4, true) }
+        LH_TRY(1, 1, true) LH_TRY(1, 2, true) LH_TRY(1, 3, true) LH_TRY(1, 4, true)
+        LH_TRY(2, 1, true) LH_TRY(2, 2, true) LH_TRY(1, 1, false) LH_TRY(1, 2, false)
 #undef LH_TRY
     }
 #endif

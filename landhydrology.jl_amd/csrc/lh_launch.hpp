@@ -9,7 +9,7 @@ enum { MATH_FAST = 0, MATH_LIBM = 1 };
 template <int CPL_, int PF_, bool NT_> struct KCfg;
 // production launch shape per working type (chosen by measurement)
 template <typename FT> struct DefaultCfg;
-template <> struct DefaultCfg<double> { using type = KCfg<1, 1, false>; };
+template <> struct DefaultCfg<double> { using type = KCfg<1, 2, false>; }; // 2 levels in flight: -2..3 % (profiles/round1_tune_prefetch.txt)
 template <> struct DefaultCfg<float> { using type = KCfg<2, 1, false>; };
 
 // run-time launch overrides (LH_TUNE environment variable; tuning builds only
