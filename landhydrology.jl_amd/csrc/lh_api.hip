@@ -42,8 +42,18 @@ struct HostParams {
 struct lh_state {
     lh_ctx* ctx;
     uint32_t mask;
-    void* plane[LH_NVARS]; // what kernels address
-    void* raw[LH_NVARS];   // what hipMalloc returned (plane = raw + stagger)
+    void* plane[LH_NVARS]; // what kernels address (a slot of a context arena)
+};
+
+// Planes are carved from a few large device allocations (8 plane slots each)
+// instead of one hipMalloc per plane: states that are streamed together then sit
+// next to each other in one contiguous range, and state creation costs no
+// allocator round trip.
+struct PlaneArena {
+    char* base = nullptr;
+    size_t slot_bytes = 0;
+    int nslots = 0;
+    std::vector<char> used;
 };
 
 struct lh_ctx {
@@ -65,6 +75,7 @@ struct lh_ctx {
     int math = MATH_FAST;
     Tune tune;
     unsigned plane_counter = 0;
+    std::vector<PlaneArena> arenas;
     std::vector<double> zc_host;
     std::string err;
     std::vector<lh_state*> states;
@@ -210,6 +221,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
     if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;
+    if ((q = strstr(t, "arena=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 1 && v <= 64) tu.arena = v;
     if ((q = strstr(t, "pad=")) && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
 }
 
@@ -295,30 +307,71 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
     return LH_OK;
 }
 
+constexpr int ARENA_SLOTS = 8;
+
+void* plane_alloc(lh_ctx* c, size_t bytes) {
+    const size_t pad = c->tune.pad >= 0 ? size_t(c->tune.pad) : LH_PLANE_STAGGER;
+    // slot pitch: plane size rounded to 2 MiB, plus the stagger (LH_TUNE pad=, a multiple of 256 B)
+    const size_t slot = (((bytes + (size_t(2) << 20) - 1) >> 21) << 21) + pad;
+    for (auto& a : c->arenas)
+        if (a.slot_bytes == slot)
+            for (int k = 0; k < a.nslots; ++k)
+                if (!a.used[k]) {
+                    a.used[k] = 1;
+                    return a.base + size_t(k) * slot;
+                }
+    PlaneArena a;
+    a.slot_bytes = slot;
+    a.nslots = c->tune.arena > 0 ? c->tune.arena : ARENA_SLOTS;
+    // small ensembles: one slot per arena would waste nothing, but keep it uniform
+    if (hipMalloc(reinterpret_cast<void**>(&a.base), slot * size_t(a.nslots)) != hipSuccess) {
+        (void)hipGetLastError();
+        a.nslots = 1; // memory is tight: fall back to a single-plane arena
+        if (hipMalloc(reinterpret_cast<void**>(&a.base), slot) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    a.used.assign(a.nslots, 0);
+    a.used[0] = 1;
+    c->arenas.push_back(a);
+    return c->arenas.back().base;
+}
+
+void plane_free(lh_ctx* c, void* p) {
+    for (size_t i = 0; i < c->arenas.size(); ++i) {
+        PlaneArena& a = c->arenas[i];
+        char* q = static_cast<char*>(p);
+        if (q >= a.base && q < a.base + a.slot_bytes * size_t(a.nslots)) {
+            a.used[(q - a.base) / a.slot_bytes] = 0;
+            bool any = false;
+            for (char u : a.used) any = any || u;
+            if (!any) { // release an arena once its last plane is gone
+                (void)hipFree(a.base);
+                c->arenas.erase(c->arenas.begin() + i);
+            }
+            return;
+        }
+    }
+}
+
 int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
     lh_state* s = new (std::nothrow) lh_state();
     if (!s) return fail(c, LH_ENOMEM, "out of host memory");
     s->ctx = c;
     s->mask = mask;
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
-    // Planes that are streamed together (Y, dY, stage states) are staggered in
-    // the address space: large allocations come back 2-MiB aligned, so the same
-    // (level, column) of every plane would otherwise share its low address bits
-    // -- and with them HBM channel and bank -- in all concurrent streams.
-    const size_t pad = c->tune.pad >= 0 ? size_t(c->tune.pad) : LH_PLANE_STAGGER;
+    for (int i = 0; i < LH_NVARS; ++i) s->plane[i] = nullptr;
     for (int i = 0; i < LH_NVARS; ++i) {
-        s->plane[i] = s->raw[i] = nullptr;
         if (mask & (1u << i)) {
-            const size_t shift = pad * size_t(c->plane_counter++ % 8);
-            hipError_t e = hipMalloc(&s->raw[i], bytes + 8 * pad);
-            if (e != hipSuccess) {
+            s->plane[i] = plane_alloc(c, bytes);
+            if (!s->plane[i]) {
                 for (int j = 0; j < i; ++j)
-                    if (s->raw[j]) (void)hipFree(s->raw[j]);
+                    if (s->plane[j]) plane_free(c, s->plane[j]);
                 delete s;
-                return fail(c, LH_ENOMEM, "hipMalloc of a %zu-byte plane failed: %s", bytes, hipGetErrorString(e));
+                return fail(c, LH_ENOMEM, "device allocation of a %zu-byte plane failed", bytes);
             }
-            s->plane[i] = static_cast<char*>(s->raw[i]) + shift;
-            e = hipMemsetAsync(s->plane[i], 0, bytes, c->stream);
+            hipError_t e = hipMemsetAsync(s->plane[i], 0, bytes, c->stream);
             if (e != hipSuccess) return fail(c, LH_ENODEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
         }
     }
@@ -329,7 +382,7 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
 
 void state_free(lh_ctx* c, lh_state* s) {
     for (int i = 0; i < LH_NVARS; ++i)
-        if (s->raw[i]) (void)hipFree(s->raw[i]);
+        if (s->plane[i]) plane_free(c, s->plane[i]);
     for (size_t i = 0; i < c->states.size(); ++i)
         if (c->states[i] == s) {
             c->states.erase(c->states.begin() + i);
@@ -540,7 +593,10 @@ int lh_set_bottom_sign_consistent(lh_ctx* c, int32_t flag) {
 
 int lh_set_tuning(lh_ctx* c, const char* spec) {
     if (!c || !spec) return LH_EINVAL;
+    const int arena = c->tune.arena, pad = c->tune.pad; // allocation policy is fixed at lh_create
     parse_tune(c->tune, spec);
+    c->tune.arena = arena;
+    c->tune.pad = pad;
     return LH_OK;
 }
 

@@ -17,6 +17,7 @@ template <> struct DefaultCfg<float> { using type = KCfg<2, 1, false>; };
 struct Tune {
     int block = 0, cpl = 0, pf = 0, nt = -1;
     int pad = -1; // plane address stagger in bytes (state allocation)
+    int arena = 0; // plane slots per device allocation (0 = default)
 };
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)

@@ -130,3 +130,38 @@ def test_bottom_sign_flag():
     got = pc.run_gpu_rhs(case)
     want = pc.run_oracle_rhs(case)
     pc.assert_tendencies_close(case, got, want, CW)
+
+
+def test_state_arena_reuse_and_isolation():
+    """States are carved from shared arenas: creating/destroying many must neither
+    alias live planes nor leak slots."""
+    import ctypes as C
+    case = pc.make_case("c2_richards_f64", ncols=300)
+    n = case.om.nlev
+    rng = np.random.default_rng(7)
+    with pc.GpuModel(case) as g:
+        F = g.F
+        live = {}
+        for it in range(40):
+            st = g.state(0)
+            a = rng.standard_normal((300, n))
+            b = rng.standard_normal((300, n))
+            g.upload(st, F.LH_VAR_VARTHETA_L, a)
+            g.upload(st, F.LH_VAR_THETA_I, b)
+            live[it] = (st, a, b)
+            if it % 3 == 2:                      # free an older one: its slots get reused
+                k = sorted(live)[0]
+                F.check(g.L.lh_state_destroy(g.ctx, live[k][0]), g.ctx)
+                g._states.remove(live[k][0])
+                del live[k]
+        for st, a, b in live.values():
+            assert np.array_equal(g.download(st, F.LH_VAR_VARTHETA_L), a)
+            assert np.array_equal(g.download(st, F.LH_VAR_THETA_I), b)
+        # device pointers of live planes are pairwise distinct
+        ptrs = []
+        for st, _, _ in live.values():
+            for v in (F.LH_VAR_VARTHETA_L, F.LH_VAR_THETA_I):
+                p = C.c_void_p()
+                F.check(g.L.lh_state_device_ptr(g.ctx, st, v, C.byref(p), None, None), g.ctx)
+                ptrs.append(p.value)
+        assert len(set(ptrs)) == len(ptrs)
