@@ -91,8 +91,14 @@ def cpu_baseline(case, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 2000:
             break
+    import shutil
+    julia = shutil.which("julia")
     return {"value": sample * n * reps / el, "unit": "cell-updates/s", "cores": threads,
             "kind": "port",
+            "reference_julia": ("julia found at %s but LandHydrology.jl's un-vendored dependencies "
+                                "(ClimaCore, CLIMAParameters, OrdinaryDiffEq) are not shipped with this "
+                                "repository: reference CPU path not timed" % julia) if julia
+            else "reference CPU path: unavailable on this host (no julia binary)",
             "sample": f"{reps} RHS evals of the first {sample} columns x {n} levels of the same "
                       f"workload, OpenMP over columns on {threads} threads ({el:.1f} s)"}
 

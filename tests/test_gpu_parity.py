@@ -165,3 +165,28 @@ def test_state_arena_reuse_and_isolation():
                 F.check(g.L.lh_state_device_ptr(g.ctx, st, v, C.byref(p), None, None), g.ctx)
                 ptrs.append(p.value)
         assert len(set(ptrs)) == len(ptrs)
+
+
+def test_planes_larger_than_4_GiB():
+    """5e6 columns x 128 levels (Float64): every plane is 5.1 GB, past any 32-bit
+    byte offset.  Sampled parity with the oracle plus the zero-flux telescoping
+    property over the whole batch."""
+    import dataclasses
+    N, name = 5_000_000, "c4_richards_f64_128"
+    case = pc.make_case(name, ncols=N)
+    with pc.GpuModel(case) as g:
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        g.rhs(Y, Ya, dY)
+        assert g.status() == 0
+        d = g.tendencies(dY)
+    assert np.all(d["ti"] == 0)
+    col = np.abs(d["vl"].sum(axis=1))
+    mag = np.abs(d["vl"]).sum(axis=1) + 1e-300
+    assert np.max(col / mag) < 64 * np.finfo(np.float64).eps * 128
+    idx = np.unique(np.concatenate([np.arange(0, 4096), np.linspace(0, N - 1, 3000).astype(np.int64),
+                                    np.arange(N - 4096, N)]))
+    sl = lambda a: None if a is None else np.ascontiguousarray(a[idx])
+    sub = dataclasses.replace(case, ncols=len(idx), vl=sl(case.vl), ti=sl(case.ti))
+    want = pc.run_oracle_rhs(sub, nthreads=8)
+    pc.assert_tendencies_close(sub, {k: v[idx] for k, v in d.items()}, want, CW, label="[5e6 x 128]")
