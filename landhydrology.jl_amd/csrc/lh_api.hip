@@ -222,6 +222,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
     if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;
     if ((q = strstr(t, "arena=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 1 && v <= 64) tu.arena = v;
+    if ((q = strstr(t, "rowpad=")) && sscanf(q + 7, "%d", &v) == 1 && v >= 0 && v % 2 == 0) tu.rowpad = v;
     if ((q = strstr(t, "pad=")) && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
 }
 
@@ -452,13 +453,25 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
     c->cfg = *cfg;
     c->device = dev;
     c->esize = cfg->dtype == LH_F64 ? 8 : 4;
-    c->stride = (cfg->ncols + 63) / 64 * 64;
+    // Plane row length: whole 512-B units, and an ODD number of them.  The column
+    // kernel has every level of a plane in flight at once (waves drift apart), so
+    // a level stride with a large power-of-two factor piles those streams onto
+    // the same HBM channels/banks: 2^20 columns ran at 59.5 % of peak with the
+    // natural 8-MiB stride and at 65-66 % with one extra unit (profiles/
+    // round1_placement_notes.txt).
+    {
+        const int64_t unit = 512 / int64_t(c->esize); // elements per 512 B
+        int64_t units = (cfg->ncols + unit - 1) / unit;
+        if (units % 2 == 0) ++units;
+        c->stride = units * unit;
+    }
     // reference defaults: loam vanGenuchten, default SoilParams
     c->hp.vg = lh_vg_params{1.56, 3.6, 0.0, 2.9e-7};
     c->hp.soil = lh_soil_params{0.43, 1e-3, 0.0, 0.0, 0.41, 2700.0, 3.97, 2700.0, 1.72, 3.13, 0.24, 18.1, 0.053};
     if (const char* m = getenv("LH_MATH"))
         if (!strcmp(m, "libm")) c->math = MATH_LIBM;
     if (const char* t = getenv("LH_TUNE")) parse_tune(c->tune, t);
+    if (c->tune.rowpad >= 0) c->stride += c->tune.rowpad; // explicit row padding (elements)
 
 #define CREATE_HIP(call)                                                                           \
     do {                                                                                           \
@@ -593,10 +606,11 @@ int lh_set_bottom_sign_consistent(lh_ctx* c, int32_t flag) {
 
 int lh_set_tuning(lh_ctx* c, const char* spec) {
     if (!c || !spec) return LH_EINVAL;
-    const int arena = c->tune.arena, pad = c->tune.pad; // allocation policy is fixed at lh_create
+    const int arena = c->tune.arena, pad = c->tune.pad, rowpad = c->tune.rowpad; // fixed at lh_create
     parse_tune(c->tune, spec);
     c->tune.arena = arena;
     c->tune.pad = pad;
+    c->tune.rowpad = rowpad;
     return LH_OK;
 }
 

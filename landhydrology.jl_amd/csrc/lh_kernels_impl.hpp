@@ -1,9 +1,10 @@
-// lh_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched soil-column
+// lh_kernels_impl.hpp -- gfx950 (MI355X, CDNA4) kernels of the batched soil-column
 // tendency path.  No MFMA: this is a bandwidth/VALU-bound vertical stencil.
 //
 // Data layout: every variable is a plane [nlev][stride] with the
 // column index fastest, so a wavefront reads 64*CPL consecutive columns of one
-// level in one fully coalesced instruction.  One lane owns CPL whole columns
+// level in one fully coalesced instruction (CPL = 1 for Float64, 2 for Float32:
+// 8 B per lane either way).  One lane owns CPL whole columns
 // and marches bottom -> top, carrying K, h (T, kappa, rho_e_l K) of the previous
 // cell and the previous face flux in registers: each face flux is computed once
 // and differenced, which keeps the discrete mass/energy conservation the

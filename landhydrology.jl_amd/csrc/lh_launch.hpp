@@ -18,6 +18,7 @@ struct Tune {
     int block = 0, cpl = 0, pf = 0, nt = -1;
     int pad = -1; // plane address stagger in bytes (state allocation)
     int arena = 0; // plane slots per device allocation (0 = default)
+    int rowpad = -1; // extra elements per plane row (-1 = library default)
 };
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)

@@ -28,7 +28,7 @@ pads = os.environ.get("PADS", "").split(",") if os.environ.get("PADS") else [Non
 nmodels = len(pads)
 for k in range(nmodels):
     if pads[k] is not None:
-        os.environ["LH_TUNE"] = f"pad={pads[k]}"
+        os.environ["LH_TUNE"] = f"{os.environ.get('PADKEY', 'pad')}={pads[k]}"
     g = pc.GpuModel(case)
     Y, Ya = g.prognostic_and_aux()
     dY = g.state(0)
@@ -41,7 +41,7 @@ for rnd in range(3):
     for cfg in cfgs:
         for k, (g, Y, Ya, dY) in enumerate(models):
             F, L, ctx = g.F, g.L, g.ctx
-            F.check(L.lh_set_tuning(ctx, (cfg + (f",pad={pads[k]}" if pads[k] is not None else "")).encode()), ctx)
+            F.check(L.lh_set_tuning(ctx, cfg.encode()), ctx)
             for _ in range(5):
                 g.rhs(Y, Ya, dY)
             if rnd == 0 and k == 0:
