@@ -224,8 +224,14 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                         r[j] = u[j] + dt * k[j];
                     else if (MODE == 2)
                         r[j] = (FT(3) * b[j] + u[j] + dt * k[j]) * FT(0.25);
-                    else
-                        r[j] = (b[j] + FT(2) * u[j] + FT(2) * dt * k[j]) * FT(1.0 / 3.0);
+                    else {
+                        // s / 3 as s*(1/3) plus one residual correction: a bare multiply by
+                        // the rounded 1/3 biases every step by 5.5e-17 and the total mass
+                        // drifts (1.6e-11 after 138 240 steps); this form is unbiased
+                        const FT sum = b[j] + FT(2) * u[j] + FT(2) * dt * k[j];
+                        const FT q = sum * FT(1.0 / 3.0);
+                        r[j] = fma_ft(fma_ft(FT(-3), q, sum), FT(1.0 / 3.0), q);
+                    }
                 }
                 vstore<FT, CPL, NT>(orow + lane_off, r);
             };
