@@ -86,6 +86,13 @@ float run(double* d[4], long ncols, long stride, int nlev, int reps) {
     return ms / reps;
 }
 
+// plain device copy, 16 B per lane, contiguous: the "measured copy ceiling" for the same bytes
+__global__ void __launch_bounds__(256) copy16(const dbl2* __restrict__ in, dbl2* __restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
 int main(int argc, char** argv) {
     const long ncols = argc > 1 ? atol(argv[1]) : 1000000;
     const int nlev = argc > 2 ? atoi(argv[2]) : 64;
@@ -101,6 +108,16 @@ int main(int argc, char** argv) {
 #define PLINE(W) { float ms = run_pair<W>(d, ncols, stride, nlev, 20); \
         printf("round %d  %-11s work=%3d  %.4f ms  %7.1f GB/s  %.1f%% of 8 TB/s\n", round, "level-pair", W, ms, gb / (ms * 1e-3), gb / (ms * 1e-3) / 80.0); }
         PLINE(0) PLINE(40)
+        {   // copy planes 0,1 -> 2,3 as two contiguous 16-B/lane copies (same 2 R + 2 W bytes)
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            const long n2 = (long)nlev * stride / 2;
+            for (int w = 0; w < 2; ++w) { copy16<<<8192, 256>>>((const dbl2*)d[0], (dbl2*)d[2], n2); copy16<<<8192, 256>>>((const dbl2*)d[1], (dbl2*)d[3], n2); }
+            hipEventRecord(e0);
+            for (int r = 0; r < 20; ++r) { copy16<<<8192, 256>>>((const dbl2*)d[0], (dbl2*)d[2], n2); copy16<<<8192, 256>>>((const dbl2*)d[1], (dbl2*)d[3], n2); }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+            printf("round %d  %-11s           %.4f ms  %7.1f GB/s  %.1f%% of 8 TB/s\n", round, "plain copy", ms, gb / (ms * 1e-3), gb / (ms * 1e-3) / 80.0);
+        }
     }
     return 0;
 }
