@@ -6,8 +6,9 @@ lh_rhs launch over one batch: `rhs!(dY, Y, Ya, t)` for every column.  Workload a
 every N: BASELINE config C2 per GPU -- 1e6 independent 64-layer Richards columns,
 Float64, loam van Genuchten, zero-flux BCs, synthetic wetting-front state
  -- i.e. weak scaling, columns block-partitioned over ranks, no
-data-path collective; the global stable-dt min all-reduce (RCCL) runs once per
-three RHS evals (= once per SSPRK33 step) inside the timed region when N > 1.
+data-path collective.  Every third evaluation (= once per SSPRK33 step) is the fused
+lh_rhs_stable_dt launch at every N; for N > 1 its one-value result is
+min-all-reduced over RCCL inside the timed region.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -143,11 +144,16 @@ def main():
     # device scalar for the stable-dt min all-reduce (FT-sized, torch-owned)
     tdt = torch.zeros(1, device="cuda", dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
 
+    # Every rank does the same work at every N (weak scaling): every third evaluation --
+    # once per SSPRK33 step -- is lh_rhs_stable_dt, which also leaves this rank's
+    # stable-step bound in device memory from the same pass; for N > 1 that one FT
+    # value is min-all-reduced over RCCL (no host round trip, no second sweep).
     def rhs_step(i):
-        F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
-        if world > 1 and i % 3 == 2:     # once per SSPRK33 step
-            F.check(L.lh_stable_dt_device(ctx, Y, Ya, 0.5, tdt.data_ptr()), ctx)
-            pkg.partition.global_min_dt(tdt)
+        if i % 3 == 2:
+            F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, 0.5, tdt.data_ptr()), ctx)
+            pkg.partition.global_min_dt(tdt)     # no-op for a single rank
+        else:
+            F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
 
     def barrier():
         if world > 1:
@@ -214,8 +220,9 @@ def main():
                                f"{'coupled water+heat' if a.workload == 'c3' else 'Richards'} columns per GPU "
                                f"({WORKLOADS[a.workload][2]}), one lh_rhs launch per step",
                    "columns_per_gpu": a.ncols, "levels": nlev,
-                   "partition": f"block over {world} rank(s); stable-dt RCCL min all-reduce every 3rd eval"
-                   if world > 1 else "single GPU"},
+                   "partition": (f"block over {world} rank(s); " if world > 1 else "single GPU; ") +
+                   "every 3rd eval also yields the rank's stable dt (fused)" +
+                   ("; RCCL min all-reduce of that value" if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "bytes_per_cell": bytes_per_cell,

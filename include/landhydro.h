@@ -201,6 +201,12 @@ int lh_coordinates(const lh_ctx*, double* zc_host);
  * it uploads Ya when its closures depend on t. */
 int lh_rhs(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY);
 
+/* lh_rhs plus, from the same pass over the state, this rank's stable-step bound
+ * (the rule of lh_stable_dt) left in device memory (one FT value): the input of
+ * the RCCL min all-reduce costs no second sweep over the columns. */
+int lh_rhs_stable_dt(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY,
+                     double courant, void* dt_device_ft);
+
 /* centre fields K, psi, kappa, T of the same pointwise stage
  * (right_hand_side.jl:156-167, 291-314) into a 4-plane state (LH_DIAG_*) */
 int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out);

@@ -78,6 +78,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_int64)]),
     "lh_coordinates": (C.c_int, [_P, _DP]),
     "lh_rhs": (C.c_int, [_P, C.c_double, _P, _P, _P]),
+    "lh_rhs_stable_dt": (C.c_int, [_P, C.c_double, _P, _P, _P, C.c_double, _P]),
     "lh_diagnostics": (C.c_int, [_P, _P, _P, _P]),
     "lh_step_ssprk33": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, _DP]),
     "lh_step_ssprk33_device_dt": (C.c_int, [_P, _P, _P, C.c_double, _P, _DP]),

@@ -209,6 +209,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.consistent_bottom_sign = h.consistent_bottom_sign;
     P.status = c->d_status;
     P.math_tab = c->d_math_tab;
+    P.dt_out = nullptr;
     return P;
 }
 
@@ -296,8 +297,10 @@ Planes<FT> planes_of(const lh_state* s) {
 
 template <typename FT>
 int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
-           double dt, int mode, const double* bc_override, const void* dt_device = nullptr) {
+           double dt, int mode, const double* bc_override, const void* dt_device = nullptr,
+           void* dt_out = nullptr) {
     DevParams<FT> P = make_params<FT>(c);
+    P.dt_out = dt_out;
     if (bc_override)
         for (int f = 0; f < 2; ++f)
             for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);
@@ -373,7 +376,12 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
                 return fail(c, LH_ENOMEM, "device allocation of a %zu-byte plane failed", bytes);
             }
             hipError_t e = hipMemsetAsync(s->plane[i], 0, bytes, c->stream);
-            if (e != hipSuccess) return fail(c, LH_ENODEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+            if (e != hipSuccess) {
+                for (int j = 0; j <= i; ++j)
+                    if (s->plane[j]) plane_free(c, s->plane[j]);
+                delete s;
+                return fail(c, LH_ENODEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+            }
         }
     }
     c->states.push_back(s);
@@ -532,6 +540,8 @@ int lh_destroy(lh_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     while (!c->states.empty()) state_free(c, c->states.back());
+    for (auto& a : c->arenas) (void)hipFree(a.base); // none should be left
+    c->arenas.clear();
     for (int i = 0; i < LH_PC_COUNT; ++i)
         if (c->d_pc[i]) (void)hipFree(c->d_pc[i]);
     for (int f = 0; f < 2; ++f)
@@ -740,6 +750,23 @@ int lh_rhs(lh_ctx* c, double t, const lh_state* Y, const lh_state* Ya, lh_state*
                                   : do_rhs<float>(c, Y, Ya, nullptr, dY, 0.0, 0, nullptr);
 }
 
+int lh_rhs_stable_dt(lh_ctx* c, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY,
+                     double courant, void* dt_device_ft) {
+    (void)t;
+    if (!c || !dt_device_ft) return fail(c, LH_EINVAL, "lh_rhs_stable_dt: NULL argument");
+    if (!(courant > 0)) return fail(c, LH_EINVAL, "lh_rhs_stable_dt: courant must be > 0");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, dY, pm, "dY"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    return c->cfg.dtype == LH_F64
+               ? do_rhs<double>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft)
+               : do_rhs<float>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft);
+}
+
 int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* out) {
     if (!c) return LH_EINVAL;
     int rc;
@@ -771,7 +798,8 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     if ((rc = check_state(c, Y, pm, "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
-    if (!c->scratch_u1 && (rc = state_alloc(c, pm, &c->scratch_u1))) return rc;
+    // the stage state carries no theta_i plane: the fused stages read theta_i from Y
+    if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
     for (int64_t s = 0; s < nsteps; ++s) {
         for (int stage = 0; stage < 3; ++stage) {
@@ -797,7 +825,7 @@ int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double
     if ((rc = check_state(c, Y, pm, "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
-    if (!c->scratch_u1 && (rc = state_alloc(c, pm, &c->scratch_u1))) return rc;
+    if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
     for (int stage = 0; stage < 3; ++stage) {
         const double* ov = bcv ? bcv + stage * 4 : nullptr;

@@ -131,10 +131,13 @@ __device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<
 // i.e. two logarithms and three exponentials per cell instead of four pows and
 // a reciprocal, and no second cancellation in S^(-1/m) - 1.  With ice (Se != S)
 // psi takes its own log2(Se), 2^(.), log2(1 - .).
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
+// WANT_DPSI additionally returns dpsi/dvl for the stable-step bound: with
+// u = S^(-1/m) - 1 = w/t the van Genuchten slope |psi| (u+1)/(n m u Se (nu_eff - theta_r))
+// collapses to |psi| / (n m w (vl_safe - theta_r)); 1/S_s when saturated.
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                                   FT& psi) {
+                                                   FT& psi, FT* dpsi = nullptr) {
     const FT nu_eff = c.nu - ti;
     const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps), NaN kept
     const FT num = vls - c.theta_r;
@@ -149,19 +152,28 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         const FT Lw = mm.log2(w);
         const FT inner = FT(1) - mm.exp2_scaled(c.e_m * Lw);
         K = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
-        if (WANT_PSI && same) psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
+        if (WANT_PSI && same) {
+            psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
+            if (WANT_DPSI) *dpsi = -psi * mm.rcp(c.n * c.m * w * num);
+        }
     } else {
         K = c.Ksat; // K_r = 1
-        if (WANT_PSI && same) psi = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+        if (WANT_PSI && same) {
+            psi = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            if (WANT_DPSI) *dpsi = c.inv_S_s;
+        }
     }
     if (WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
         const FT Se = num * mm.rcp(nu_eff - c.theta_r);
         if (Se < FT(1)) {
             const FT ae = mm.log2(Se) * c.e_inv_m;
-            const FT Lwe = mm.log2(FT(1) - mm.exp2_scaled(ae));
+            const FT we = FT(1) - mm.exp2_scaled(ae);
+            const FT Lwe = mm.log2(we);
             psi = -mm.exp2_scaled(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
+            if (WANT_DPSI) *dpsi = -psi * mm.rcp(c.n * c.m * we * num);
         } else {
             psi = (Se == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            if (WANT_DPSI) *dpsi = c.inv_S_s;
         }
     }
     if (FACTORS) {
@@ -178,12 +190,25 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true>
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                               FT& psi) {
-    if (M::is_production) water_closures_log<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
-    else water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
+                                               FT& psi, FT* dpsi = nullptr) {
+    if (M::is_production) {
+        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI>(mm, P, c, vl, ti, T, K, psi, dpsi);
+    } else {
+        water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
+        if (WANT_DPSI) { // as the oracle writes it
+            const FT nu_eff = c.nu - ti;
+            const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
+            const FT Se = (vls - c.theta_r) / (nu_eff - c.theta_r);
+            const FT u = mm.pow(Se, -c.inv_m) - FT(1);
+            if (Se <= FT(1) && u > FT(0))
+                *dpsi = fabs(psi) * (u + FT(1)) / (c.n * c.m * u * Se * (nu_eff - c.theta_r));
+            else
+                *dpsi = FT(1) / c.S_s;
+        }
+    }
 }
 
 // T, kappa (and rho_c_s) of one cell: right_hand_side.jl:291-305 with
@@ -243,7 +268,8 @@ template <typename FT, typename M, int MODEL, bool FACTORS>
 __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>& P,
                                                 const ColC<FT>& c, int face, int64_t col, FT vl_c,
                                                 FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
-                                                FT& f_w) {
+                                                FT& f_w, FT* K_face = nullptr,
+                                                FT* kappa_face = nullptr) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     const int ke = P.bc_kind[face][COMP_ENERGY];
@@ -266,6 +292,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
         } else if (ke == BC_DIRICHLET) { // :416-444
             FT kap_f = kappa_closure<FT, M>(mm, P, c, vl_f, ti_c);
             f_e = sgn * (-kap_f * (T_f - T_c) / dzb);
+            if (kappa_face) *kappa_face = kap_f;
         }
     }
     if (WATER) {
@@ -276,6 +303,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
         } else if (kh == BC_DIRICHLET) { // :371-401
             FT K_f, psi_f;
             water_closures<FT, M, FACTORS>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f);
+            if (K_face) *K_face = K_f;
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
                 f_w = K_f * (psi_f - psi_c - dzb) / dzb;
             else

@@ -85,6 +85,16 @@ __device__ __forceinline__ MathTables stage_math_tables(const double* gtab, doub
     return t;
 }
 
+// positive IEEE values order like their bit patterns: global minima are integer atomicMin
+template <typename FT> struct Bits;
+template <> struct Bits<double> { using type = unsigned long long; };
+template <> struct Bits<float> { using type = unsigned int; };
+
+__device__ __forceinline__ double fmax_ft(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fmax_ft(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmin_ft(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fmin_ft(float a, float b) { return __builtin_fminf(a, b); }
+
 template <typename FT>
 __device__ __forceinline__ bool finite(FT x) {
     return x - x == FT(0);
@@ -98,6 +108,9 @@ __device__ __forceinline__ bool finite(FT x) {
 // boundary faces replaced by the boundary fluxes (SetValue).
 //
 // MODE 0: write the tendency dY.
+// MODE 4: MODE 0 plus the local stable-step bound of the same state (the rule of
+//         stable_dt_kernel, from the K, dpsi/dvl, kappa, rho_c_s this pass has in
+//         registers anyway): one integer atomicMin per wave into P.dt_out.
 // MODE 1..3: fused SSPRK33 stage s (OrdinaryDiffEq SSPRK33, Shu-Osher form):
 //   1: U1 = Y + dt f(Y)              (in = Y,  out = U1)
 //   2: U1 = (3 Y + U1 + dt f(U1))/4  (in = U1, base = Y, out = U1)
@@ -115,18 +128,24 @@ template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typen
 __global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
-    // the step size either comes by value or is read from device memory, where a
-    // preceding stable-dt reduction / RCCL min all-reduce left it (no host sync)
-    const FT dt = (MODE != 0 && dt_device) ? *dt_device : dt_value;
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     constexpr int CPL = CFG::CPL, PF = CFG::PF;
     constexpr bool NT = CFG::NT;
+    constexpr bool TEND = (MODE == 0 || MODE == 4); // writes a tendency (not a stage state)
+    constexpr bool WANT_DT = (MODE == 4);
+    // the step size either comes by value or is read from device memory, where a
+    // preceding stable-dt reduction / RCCL min all-reduce left it (no host sync)
+    const FT dt = (!TEND && dt_device) ? *dt_device : dt_value; // MODE 4: dt_value = courant
     __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
     extern __shared__ __align__(16) unsigned char s_dyn[];
     FT* s_zc = reinterpret_cast<FT*>(s_dyn);
     const int n = P.nlev;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_zc[i] = P.zc[i];
+    // MODE 4: one LDS word per thread for the wave-level minimum (after the level
+    // coordinates, 16-byte aligned); lanes past the last column leave +inf there
+    FT* s_red = reinterpret_cast<FT*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
+    if (WANT_DT) s_red[threadIdx.x] = FT(INFINITY);
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
 
@@ -138,14 +157,14 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     // uniform row pointers (level 0); HEAT reads the prescribed water fields from
     // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
     const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]);
-    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (MODE == 0 ? IN.v[1] : BASE.v[1]));
+    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1]));
     const FT* r_re = HEAT ? IN.v[2] : nullptr;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     const FT* r_Ta = need_Taux ? AUX.v[3] : nullptr;
-    const FT* b_vl = (MODE >= 2 && WATER) ? BASE.v[0] : nullptr;
-    const FT* b_re = (MODE >= 2 && HEAT) ? BASE.v[2] : nullptr;
+    const FT* b_vl = ((MODE == 2 || MODE == 3) && WATER) ? BASE.v[0] : nullptr;
+    const FT* b_re = ((MODE == 2 || MODE == 3) && HEAT) ? BASE.v[2] : nullptr;
     FT* o_vl = WATER ? OUT.v[0] : nullptr;
-    FT* o_ti = (WATER && MODE == 0) ? OUT.v[1] : nullptr;
+    FT* o_ti = (WATER && TEND) ? OUT.v[1] : nullptr;
     FT* o_re = HEAT ? OUT.v[2] : nullptr;
 
     ColC<FT> c[CPL];
@@ -162,6 +181,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
     FT nf_acc = FT(0); // += 0 * tendency: becomes NaN once any tendency is non-finite
+    FT dpsi_p[CPL], rcs_p[CPL], Dmax[CPL]; // MODE 4: stable-step bookkeeping
 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -169,6 +189,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         vl_p[j] = re_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
         Ta[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
+        dpsi_p[j] = Dmax[j] = FT(0);
+        rcs_p[j] = FT(1);
     }
     // loads the level the row pointers currently address into ring slot `slot`,
     // then moves the pointers one level up
@@ -205,7 +227,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                 if (HEAT) nf_acc = fma_ft(dre[j], FT(0), nf_acc);
             }
         }
-        if (MODE == 0) {
+        if (TEND) {
             if (WATER) {
                 FT zero[CPL];
 #pragma unroll
@@ -240,12 +262,12 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
         if (WATER) {
             o_vl += stride;
-            if (MODE == 0) o_ti += stride;
-            if (MODE >= 2) b_vl += stride;
+            if (TEND) o_ti += stride;
+            if (MODE == 2 || MODE == 3) b_vl += stride;
         }
         if (HEAT) {
             o_re += stride;
-            if (MODE >= 2) b_re += stride;
+            if (MODE == 2 || MODE == 3) b_re += stride;
         }
     };
 
@@ -263,28 +285,47 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
         if (i + PF < n) fetch(k); // keep PF levels in flight ahead of the one computed
         const FT z = s_zc[i];
-        FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL];
+        FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], dpsi[CPL], rcs[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             T[j] = Ta[j];
             kap[j] = FT(0);
-            K[j] = psi[j] = h[j] = E[j] = FT(0);
+            K[j] = psi[j] = h[j] = E[j] = dpsi[j] = FT(0);
+            rcs[j] = FT(1);
             if (HEAT) {
-                FT rcs;
-                T[j] = temperature_closure<FT, M>(mm, P, c[j], vl[j], ti[j], re[j], rcs);
+                T[j] = temperature_closure<FT, M>(mm, P, c[j], vl[j], ti[j], re[j], rcs[j]);
                 kap[j] = kappa_closure<FT, M>(mm, P, c[j], vl[j], ti[j]);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS>(mm, P, c[j], vl[j], ti[j], T[j], K[j], psi[j]);
+                water_closures<FT, M, FACTORS, true, WANT_DT>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
+                                                              psi[j], &dpsi[j]);
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
+            }
+            if (WANT_DT) { // the rule of stable_dt_kernel, per cell / per interior face
+                FT D = FT(0);
+                if (i == 0 || i == n - 1) {
+                    D = K[j] * dpsi[j];
+                    if (HEAT) D = fmax_ft(D, kap[j] * mm.rcp(rcs[j]));
+                }
+                if (i > 0) {
+                    D = fmax_ft(D, (K_p[j] + K[j]) * FT(0.5) * fmax_ft(dpsi_p[j], dpsi[j]));
+                    if (HEAT) D = fmax_ft(D, (kap_p[j] + kap[j]) * FT(0.5) * mm.rcp(fmin_ft(rcs_p[j], rcs[j])));
+                }
+                Dmax[j] = fmax_ft(Dmax[j], D);
             }
         }
         if (i == 0) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j)
+            for (int j = 0; j < CPL; ++j) {
+                FT K_f = FT(0), kap_f = FT(0);
                 boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
-                                                       T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j]);
+                                                       T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f);
+                if (WANT_DT) { // Dirichlet faces: half a cell away, face-state coefficients
+                    Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K[j] : FT(0)) * dpsi[j]);
+                    if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0)) * mm.rcp(rcs[j]));
+                }
+            }
         } else {
             FT Fw[CPL], Fe[CPL];
 #pragma unroll
@@ -318,18 +359,55 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             T_p[j] = T[j];
             kap_p[j] = kap[j];
             E_p[j] = E[j];
+            if (WANT_DT) {
+                dpsi_p[j] = dpsi[j];
+                rcs_p[j] = rcs[j];
+            }
         }
       }
     }
     {
         FT Fw[CPL], Fe[CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
+        for (int j = 0; j < CPL; ++j) {
+            FT K_f = FT(0), kap_f = FT(0);
             boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
-                                                   K_p[j], psi_p[j], Fe[j], Fw[j]);
+                                                   K_p[j], psi_p[j], Fe[j], Fw[j], &K_f, &kap_f);
+            if (WANT_DT) {
+                Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K_p[j] : FT(0)) * dpsi_p[j]);
+                if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap_p[j] : FT(0)) * mm.rcp(rcs_p[j]));
+            }
+        }
         emit(Fw, Fe, vl_p, re_p);
     }
     if (nf_acc != nf_acc) atomicOr(P.status, 1u);
+    if (WANT_DT) { // dt = courant dz^2 / max D over this lane's columns, min over the wave
+        using U = typename Bits<FT>::type;
+        FT best = FT(INFINITY);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if ((CPL == 1 || col0 + j < P.ncols) && Dmax[j] > FT(0)) {
+                const FT dtc = (dt * P.dz * P.dz) / Dmax[j];
+                if (dtc < best) best = dtc;
+            }
+        // Wave minimum through LDS: lanes past the last column returned early, so a
+        // cross-lane shuffle could read their dead registers; their LDS words hold
+        // +inf from the prologue.  One wave = one 64-word segment, no block barrier.
+        s_red[threadIdx.x] = best;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long active = __ballot(1);
+        const int first = __ffsll((long long)active) - 1;
+        if ((int)(threadIdx.x & 63) == first) {
+            const FT* seg = s_red + (threadIdx.x & ~63u);
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) best = fmin_ft(best, seg[l]);
+        }
+        if ((int)(threadIdx.x & 63) == first && best < FT(INFINITY)) {
+            U b;
+            __builtin_memcpy(&b, &best, sizeof(FT));
+            atomicMin(reinterpret_cast<U*>(P.dt_out), b);
+        }
+    }
 }
 
 // --------------------------------------------------------- diagnostics
@@ -368,9 +446,6 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
 // min over cells of courant*dz^2/max(K dpsi/dvl, kappa/rho_c_s) (build-defined;
 // the reference steps with a fixed user dt, simulation.jl:34-70).  Positive IEEE
 // values order like their bit patterns, so the global min is an integer atomicMin.
-template <typename FT> struct Bits;
-template <> struct Bits<double> { using type = unsigned long long; };
-template <> struct Bits<float> { using type = unsigned int; };
 
 template <typename FT, int MODEL, bool PERCOL, typename M>
 __global__ void __launch_bounds__(256)
@@ -421,9 +496,12 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
                     FT vh = P.bc_value[face][COMP_HYDROLOGY];
                     if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
                     const FT vl_f = (WATER && kh == BC_DIRICHLET) ? vh : vl;
+                    FT ve = P.bc_value[face][COMP_ENERGY];
+                    if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
+                    const FT T_f = (HEAT && ke == BC_DIRICHLET) ? ve : Tc; // as boundary_fluxes
                     if (WATER && kh == BC_DIRICHLET) {
                         FT K_f, psi_f;
-                        water_closures<FT, M, true, false>(mm, P, c, vl_f, ti, FT(288), K_f, psi_f);
+                        water_closures<FT, M, true, false>(mm, P, c, vl_f, ti, T_f, K_f, psi_f);
                         FT Db = FT(2) * (K_f > K ? K_f : K) * dpsi;
                         if (Db > D) D = Db;
                     }
@@ -533,7 +611,9 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
                             int mode, int block, hipStream_t s) {
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
-    const unsigned dyn = (unsigned)(((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15); // z_i in LDS
+    // dynamic LDS: z_i, plus one word per thread for the mode-4 reduction
+    const unsigned dyn = (unsigned)((((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15) +
+                                    (mode == 4 ? (size_t)block * sizeof(FT) : 0));
     if (!M::is_production) { // MathLibm: tendency only
         hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
         return;
@@ -542,7 +622,11 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
         case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
         case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
         case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-        default: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+        case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+        default: // 4: tendency + stable-step bound; the minimum starts at +inf
+            hipLaunchKernelGGL((init_bits_kernel<FT>), dim3(1), dim3(1), 0, s, reinterpret_cast<typename Bits<FT>::type*>(P.dt_out));
+            hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
+            break;
     }
 }
 
@@ -602,7 +686,7 @@ void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& 
     }
     // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
     // the fused SSPRK33 stages always run the production math.
-    if (math == MATH_LIBM && mode == 0) {
+    if (math == MATH_LIBM && mode == 0) { // (mode 4 always runs the production math)
         LH_DISPATCH_MODEL(MathLibm<FT>)
     } else {
         LH_DISPATCH_MODEL(MathFast<FT>)

@@ -346,3 +346,33 @@ def test_stable_dt_matches_oracle_and_device_dt_stepping():
 def _pkg():
     import __graft_entry__ as ge
     return ge.load_package()
+
+
+@pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "c3_coupled_f64",
+                                  "mixed_smooth_f64", "c1_dirichlet_f64", "c5_percol_f64",
+                                  "heat_dirichlet_f64", "richards_viscosity_f64", "single_cell_f64",
+                                  "mixed_smooth_f32"])
+def test_fused_rhs_stable_dt(name):
+    """lh_rhs_stable_dt = lh_rhs (same tendencies, bit for bit) + the stable-step bound of
+    lh_stable_dt / the oracle's rule from the same pass."""
+    import torch
+    case = pc.make_case(name, ncols=None if name != "c1_dirichlet_f64" else 7)
+    want_dt = O.stable_dt(case.om, case.vl, case.ti, case.rhoe, 0.5, case.T_aux)
+    with pc.GpuModel(case) as g:
+        F = g.F
+        Y, Ya = g.prognostic_and_aux()
+        dA, dB = g.state(0), g.state(0)
+        g.rhs(Y, Ya, dA)
+        tdt = torch.full((1,), -1.0, device="cuda",
+                         dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
+        F.check(g.L.lh_rhs_stable_dt(g.ctx, 0.0, Y, Ya, dB, 0.5, tdt.data_ptr()), g.ctx)
+        F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+        a, b = g.tendencies(dA), g.tendencies(dB)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (name, k)
+        sep = C.c_double()
+        F.check(g.L.lh_stable_dt(g.ctx, Y, Ya, 0.5, C.byref(sep)), g.ctx)
+    got = float(tdt.item())
+    rel = 1e-11 if case.dtype == np.float64 else 2e-4
+    assert abs(got - want_dt) <= rel * want_dt, (name, got, want_dt)
+    assert abs(got - sep.value) <= rel * want_dt, (name, got, sep.value)
