@@ -31,7 +31,8 @@ using CLIMAParameters.Planet: ρ_cloud_liq, ρ_cloud_ice, cp_l, cp_i, T_0, LH_f0
 using CLIMAParameters.Atmos.Microphysics: K_therm
 import LandHydrology.SoilInterface: make_rhs
 
-export HIPBackend, ColumnEnsemble, upload, download, step_ssprk33!, stable_dt
+export HIPBackend, ColumnEnsemble, upload, download, step_ssprk33!, stable_dt, rhs_stable_dt!,
+    step_ssprk33_device_dt!
 
 const lib = get(ENV, "LANDHYDRO_HIP_LIB", "liblandhydro_hip.so")
 
@@ -213,6 +214,26 @@ function step_ssprk33!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt, nsteps)
     check(ens.ctx, ccall((:lh_step_ssprk33, lib), Cint,
                          (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Float64}),
                          ens.ctx, Y.handle, ya, t, dt, nsteps, vals))
+    return Y
+end
+
+"rhs! plus this rank's stable-step bound (one FT value at the device pointer `dt_dev`) in one launch"
+function rhs_stable_dt!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t, courant, dt_dev::Ptr{Cvoid})
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_rhs_stable_dt, lib), Cint,
+                         (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}),
+                         ens.ctx, t, Y.handle, ya, dY.handle, courant, dt_dev))
+    return dY
+end
+
+"one SSPRK33 step with dt read from device memory (after the min all-reduce of `dt_dev`)"
+function step_ssprk33_device_dt!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt_dev::Ptr{Cvoid})
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_step_ssprk33_device_dt, lib), Cint,
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Float64}),
+                         ens.ctx, Y.handle, ya, t, dt_dev, C_NULL))
     return Y
 end
 
