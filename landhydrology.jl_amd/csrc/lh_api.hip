@@ -437,6 +437,7 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
     if (!out || !cfg) return fail(nullptr, LH_EINVAL, "lh_create: NULL argument");
     *out = nullptr;
     if (cfg->ncols < 1 || cfg->nlev < 1) return fail(nullptr, LH_EINVAL, "lh_create: ncols and nlev must be >= 1");
+    if (cfg->ncols > (int64_t(1) << 28)) return fail(nullptr, LH_EINVAL, "lh_create: more than 2^28 columns per context is not supported (a plane row must stay below 4 GiB); partition the ensemble");
     if (cfg->nlev > 4096) return fail(nullptr, LH_EINVAL, "lh_create: nlev > 4096 is not supported (level coordinates are staged in LDS)");
     if (!(cfg->zmin < cfg->zmax)) return fail(nullptr, LH_EINVAL, "lh_create: zlim[1] < zlim[2] required (domain.jl:30)");
     if (cfg->dtype != LH_F32 && cfg->dtype != LH_F64) return fail(nullptr, LH_EINVAL, "lh_create: dtype must be LH_F32 or LH_F64");

@@ -12,6 +12,7 @@
 #pragma once
 #include "lh_closures.hpp"
 #include "lh_launch.hpp"
+#include <type_traits>
 
 namespace lh {
 
@@ -61,6 +62,28 @@ __device__ __forceinline__ void vstore(FT* p, const FT (&in)[N]) {
     for (int j = 0; j < N; ++j) e[j] = in[j];
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
     else *reinterpret_cast<V*>(p) = v;
+}
+
+// Row access through a buffer descriptor: a uniform row pointer (SGPRs) plus a
+// 32-bit lane byte offset -- no 64-bit vector address arithmetic, and loads or
+// stores past the end of the row are dropped by the hardware range check.
+// (hipcc otherwise turns `row + lane` into per-lane 64-bit induction variables.)
+template <typename FT, int N, bool NT>
+__device__ __forceinline__ void bload(const FT* row, unsigned row_bytes, unsigned lane_byte, FT (&out)[N]) {
+    static_assert(sizeof(FT) * N == 8, "one 8-byte access per lane");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<FT*>(row), 0, row_bytes, 0x00020000);
+    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_byte, 0, NT ? 2 : 0);
+    __builtin_memcpy(out, &v, 8);
+}
+template <typename FT, int N, bool NT>
+__device__ __forceinline__ void bstore(FT* row, unsigned row_bytes, unsigned lane_byte, const FT (&in)[N]) {
+    static_assert(sizeof(FT) * N == 8, "one 8-byte access per lane");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_bytes, 0x00020000);
+    u32x2 v;
+    __builtin_memcpy(&v, in, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, lane_byte, 0, NT ? 2 : 0);
 }
 
 // launch shape of the column kernel: columns per lane, levels kept in flight
@@ -152,7 +175,18 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     const int64_t col0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * CPL;
     if (col0 >= P.ncols) return;
     const int64_t stride = P.stride;
-    const unsigned lane_off = (unsigned)col0; // a plane row is < 2^32 elements
+    // 32-bit BYTE offset of this lane inside a plane row (lh_create bounds a row to < 4 GiB)
+    const unsigned lane_byte = (unsigned)col0 * (unsigned)sizeof(FT);
+    const unsigned row_bytes = (unsigned)(stride * (int64_t)sizeof(FT));
+    constexpr bool BUF = (sizeof(FT) * CPL == 8); // production shapes: one 8-byte access per lane
+    auto rload = [&](const FT* row, FT (&out)[CPL]) {
+        if constexpr (BUF) bload<FT, CPL, NT>(row, row_bytes, lane_byte, out);
+        else vload<FT, CPL, NT>(row + col0, out);
+    };
+    auto rstore = [&](FT* row, const FT (&in)[CPL]) {
+        if constexpr (BUF) bstore<FT, CPL, NT>(row, row_bytes, lane_byte, in);
+        else vstore<FT, CPL, NT>(row + col0, in);
+    };
 
     // uniform row pointers (level 0); HEAT reads the prescribed water fields from
     // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
@@ -195,10 +229,10 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     // loads the level the row pointers currently address into ring slot `slot`,
     // then moves the pointers one level up
     auto fetch = [&](int slot) {
-        vload<FT, CPL, NT>(r_vl + lane_off, vl_n[slot]);
-        vload<FT, CPL, NT>(r_ti + lane_off, ti_n[slot]);
-        if (HEAT) vload<FT, CPL, NT>(r_re + lane_off, re_n[slot]);
-        if (need_Taux) vload<FT, CPL, NT>(r_Ta + lane_off, Ta_n[slot]);
+        rload(r_vl, vl_n[slot]);
+        rload(r_ti, ti_n[slot]);
+        if (HEAT) rload(r_re, re_n[slot]);
+        if (need_Taux) rload(r_Ta, Ta_n[slot]);
         r_vl += stride;
         r_ti += stride;
         if (HEAT) r_re += stride;
@@ -232,14 +266,14 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                 FT zero[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) zero[j] = FT(0);
-                vstore<FT, CPL, NT>(o_vl + lane_off, dvl);
-                vstore<FT, CPL, NT>(o_ti + lane_off, zero); // d theta_i = 0 (:182, :359)
+                rstore(o_vl, dvl);
+                rstore(o_ti, zero); // d theta_i = 0 (:182, :359)
             }
-            if (HEAT) vstore<FT, CPL, NT>(o_re + lane_off, dre);
+            if (HEAT) rstore(o_re, dre);
         } else {
             auto stage = [&](const FT* brow, FT* orow, const FT (&u)[CPL], const FT (&k)[CPL]) {
                 FT b[CPL], r[CPL];
-                if (MODE != 1) vload<FT, CPL, NT>(brow + lane_off, b);
+                if (MODE != 1) rload(brow, b);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     if (MODE == 1)
@@ -255,7 +289,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                         r[j] = fma_ft(fma_ft(FT(-3), q, sum), FT(1.0 / 3.0), q);
                     }
                 }
-                vstore<FT, CPL, NT>(orow + lane_off, r);
+                rstore(orow, r);
             };
             if (WATER) stage(b_vl, o_vl, u_vl, dvl);
             if (HEAT) stage(b_re, o_re, u_re, dre);
