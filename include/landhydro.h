@@ -218,6 +218,28 @@ int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out
 int lh_step_ssprk33(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double dt,
                     int64_t nsteps, const double* bc_stage_values);
 
+/* Placement tuning -- no counterpart in the reference (host arrays have no such
+ * effect).  The speed of the column launch on MI355X depends on where in HBM the
+ * planes it streams together sit relative to each other (a few discrete rates,
+ * ~12 % apart, reproducible for a given set of plane slots, also seen by a plain
+ * device copy).  This call times the real launch on the data in Y with the
+ * WRITTEN state in up to max_candidates (0 = default 6) different slot sets and
+ * keeps the fastest:
+ *   dY != NULL: the tendency launch of lh_rhs / lh_rhs_stable_dt writing dY;
+ *   dY == NULL: the fused SSPRK33 stages of lh_step_ssprk33* writing the context's
+ *               internal stage state (the trial stages run with dt = 0).
+ * With LH_PLACE_MOVE_INPUT in flags the planes of Y are then tried in other slots
+ * the same way (contents copied).  The values in Y never change; the contents of dY
+ * are unspecified afterwards; device pointers obtained earlier from
+ * lh_state_device_ptr for a moved state (dY; Y with LH_PLACE_MOVE_INPUT) are
+ * stale.  Results of later launches do not depend on the placement.  One-off cost:
+ * ~12 launches per candidate and (max_candidates-1) temporary copies of the moved
+ * state.  ms_before/ms_after (optional): launch time with the original and the
+ * chosen placement.  Synchronises. */
+#define LH_PLACE_MOVE_INPUT 1u
+int lh_tune_placement(lh_ctx*, lh_state* Y, const lh_state* Ya, lh_state* dY, int max_candidates,
+                      uint32_t flags, float* ms_before, float* ms_after);
+
 /* One SSPRK33 step whose dt is read from DEVICE memory (one FT value, e.g. the
  * output of lh_stable_dt_device after an RCCL min all-reduce): adaptive stepping
  * across ranks without a host round trip.  bc_stage_values: NULL or [3][2][2]. */

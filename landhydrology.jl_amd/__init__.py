@@ -14,6 +14,6 @@ from .soil import (Column, Dirichlet, EarthParameterSet, FieldVector, Float32, F
                    SoilColumnBC, SoilComponentBC, SoilEnergyModel, SoilHydrologyModel, SoilModel,
                    SoilParams, SSPRK33, TemperatureDependentViscosity, VerticalFlux, coordinates,
                    default_initial_conditions, initialize_states, make_function_space, make_rhs,
-                   make_update_aux, run, stable_dt, step, vanGenuchten)
+                   make_update_aux, run, stable_dt, step, tune_placement, vanGenuchten)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

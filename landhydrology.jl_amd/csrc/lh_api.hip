@@ -224,7 +224,8 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;
     if ((q = strstr(t, "arena=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 1 && v <= 64) tu.arena = v;
     if ((q = strstr(t, "rowpad=")) && sscanf(q + 7, "%d", &v) == 1 && v >= 0 && v % 2 == 0) tu.rowpad = v;
-    if ((q = strstr(t, "pad=")) && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
+    for (q = strstr(t, "pad="); q; q = strstr(q + 4, "pad=")) // not the tail of "rowpad="
+        if ((q == t || q[-1] == ',' || q[-1] == ' ') && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
 }
 
 bool any_percol(const lh_ctx* c) {
@@ -420,6 +421,118 @@ int upload_percol(lh_ctx* c, void** slot, const double* host) {
     else launch_convert<float>(static_cast<float*>(*slot), tmp, n, c->stream);
     LH_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(tmp);
+    return LH_OK;
+}
+
+} // namespace
+
+// Placement tuning.  On MI355X the speed of the column kernel depends on WHERE
+// the planes it streams together sit relative to each other in HBM: the same
+// launch on the same data runs at one of a few discrete rates (e.g. 0.339 /
+// 0.378 / 0.393 ms on the 1e6 x 64 Float64 Richards case) depending on which
+// arena slots hold the written state, reproducibly for a given set of slots and
+// with no usable rule in the virtual addresses (profiles/round1_placement_notes.txt).
+// So the library measures: it times the real launch with the written state in
+// up to `max_candidates` different slot sets and keeps the fastest.
+namespace {
+
+// keep_contents: every candidate receives a copy of the target's planes (an INPUT
+// of the launch is being moved); otherwise candidates start zeroed (an output).
+template <typename RUN>
+int tune_state_planes(lh_ctx* c, lh_state* target, int max_candidates, bool keep_contents, RUN&& run,
+                      float* ms_before, float* ms_after) {
+    struct Cand {
+        void* plane[LH_NVARS];
+        float ms;
+    };
+    const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+    int nplanes = 0;
+    for (int i = 0; i < LH_NVARS; ++i) nplanes += target->plane[i] != nullptr;
+    int K = max_candidates > 0 ? max_candidates : 6;
+    if (K > 16) K = 16;
+    // every candidate stays allocated until the choice is made: keep well inside free memory
+    size_t free_b = 0, total_b = 0;
+    LH_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    const size_t per_cand = (bytes + (size_t(4) << 20)) * size_t(nplanes);
+    const size_t arena_b = (bytes + (size_t(4) << 20)) * ARENA_SLOTS;
+    while (K > 1 && size_t(K - 1) * per_cand + 2 * arena_b > free_b / 2) --K;
+
+    // the trial launches must not leave their own mark in the status word
+    uint32_t status_saved = 0;
+    LH_HIP(c, hipMemcpyAsync(&status_saved, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LH_HIP(c, hipStreamSynchronize(c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    LH_HIP(c, hipEventCreate(&e0));
+    LH_HIP(c, hipEventCreate(&e1));
+    int rc = LH_OK;
+    auto timed = [&](float& ms) -> int {
+        constexpr int REPS = 5;
+        for (int r = 0; r < 2 && !rc; ++r) rc = run();
+        if (rc) return rc;
+        if (hipEventRecord(e0, c->stream) != hipSuccess) return LH_ENODEVICE;
+        for (int r = 0; r < REPS && !rc; ++r) rc = run();
+        if (rc) return rc;
+        if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            return LH_ENODEVICE;
+        ms /= REPS;
+        return LH_OK;
+    };
+    std::vector<Cand> cands;
+    Cand cur;
+    for (int i = 0; i < LH_NVARS; ++i) cur.plane[i] = target->plane[i];
+    cur.ms = 0;
+    cands.push_back(cur);
+    for (int r = 0; r < 20 && !rc; ++r) rc = run(); // clocks up before anything is compared
+    for (int k = 1; k < K && !rc; ++k) {
+        Cand nc;
+        bool ok = true;
+        for (int i = 0; i < LH_NVARS; ++i) {
+            nc.plane[i] = nullptr;
+            if (ok && target->plane[i]) {
+                nc.plane[i] = plane_alloc(c, bytes);
+                if (!nc.plane[i]) ok = false;
+                else if ((keep_contents ? hipMemcpyAsync(nc.plane[i], cands[0].plane[i], bytes,
+                                                         hipMemcpyDeviceToDevice, c->stream)
+                                        : hipMemsetAsync(nc.plane[i], 0, bytes, c->stream)) != hipSuccess)
+                    ok = false;
+            }
+        }
+        if (!ok) { // out of memory: work with the candidates there are
+            (void)hipGetLastError();
+            for (int i = 0; i < LH_NVARS; ++i)
+                if (nc.plane[i]) plane_free(c, nc.plane[i]);
+            break;
+        }
+        nc.ms = 0;
+        cands.push_back(nc);
+    }
+    // two interleaved passes, the minimum counts
+    for (int pass = 0; pass < 2 && !rc; ++pass)
+        for (auto& cd : cands) {
+            for (int i = 0; i < LH_NVARS; ++i) target->plane[i] = cd.plane[i];
+            float ms = 0;
+            if ((rc = timed(ms))) break;
+            cd.ms = (pass == 0 || ms < cd.ms) ? ms : cd.ms;
+        }
+    size_t best = 0;
+    if (!rc)
+        for (size_t k = 1; k < cands.size(); ++k)
+            if (cands[k].ms < cands[best].ms * 0.985f) best = k; // move only for a real gain
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t k = 0; k < cands.size(); ++k) {
+        if (k == best) continue;
+        for (int i = 0; i < LH_NVARS; ++i)
+            if (cands[k].plane[i]) plane_free(c, cands[k].plane[i]);
+    }
+    for (int i = 0; i < LH_NVARS; ++i) target->plane[i] = cands[best].plane[i];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipMemcpyAsync(c->d_status, &status_saved, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    if (ms_before) *ms_before = cands[0].ms;
+    if (ms_after) *ms_after = cands[best].ms;
     return LH_OK;
 }
 
@@ -889,6 +1002,49 @@ int lh_synchronize(lh_ctx* c) {
     if (!c) return LH_EINVAL;
     (void)hipSetDevice(c->device);
     LH_HIP(c, hipStreamSynchronize(c->stream));
+    return LH_OK;
+}
+
+int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, int max_candidates,
+                      uint32_t flags, float* ms_before, float* ms_after) {
+    if (!c) return LH_EINVAL;
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    if (dY && (rc = check_state(c, dY, pm, "dY"))) return rc;
+    if (dY == Y) return fail(c, LH_EINVAL, "lh_tune_placement: dY must not be Y");
+    if (flags & ~uint32_t(LH_PLACE_MOVE_INPUT)) return fail(c, LH_EINVAL, "lh_tune_placement: unknown flag bits");
+    (void)hipSetDevice(c->device);
+    const bool f64 = c->cfg.dtype == LH_F64;
+    lh_state* written = dY;
+    if (!dY) { // the stage state of the fused SSPRK33 stepper
+        if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
+        written = c->scratch_u1;
+    }
+    auto run = [&]() -> int {
+        if (dY) // the tendency launch of lh_rhs / lh_rhs_stable_dt
+            return f64 ? do_rhs<double>(c, Y, Ya, nullptr, dY, 0.0, 0, nullptr)
+                       : do_rhs<float>(c, Y, Ya, nullptr, dY, 0.0, 0, nullptr);
+        // stages 1 and 2 with dt = 0 stream the same planes as a step and leave Y untouched
+        // (U1 = Y + 0 f(Y); U1 = (3Y + U1 + 0 f(U1))/4)
+        lh_state* U1 = c->scratch_u1;
+        int r = f64 ? do_rhs<double>(c, Y, Ya, Y, U1, 0.0, 1, nullptr)
+                    : do_rhs<float>(c, Y, Ya, Y, U1, 0.0, 1, nullptr);
+        if (r) return r;
+        return f64 ? do_rhs<double>(c, U1, Ya, Y, U1, 0.0, 2, nullptr)
+                   : do_rhs<float>(c, U1, Ya, Y, U1, 0.0, 2, nullptr);
+    };
+    float b0 = 0, a0 = 0;
+    if ((rc = tune_state_planes(c, written, max_candidates, false, run, &b0, &a0))) return rc;
+    if (flags & LH_PLACE_MOVE_INPUT) { // then the read state, against the written one just chosen
+        float b1 = 0, a1 = 0;
+        if ((rc = tune_state_planes(c, Y, max_candidates, true, run, &b1, &a1))) return rc;
+        if (a1 < a0) a0 = a1; // b1 re-measures the placement a0 was measured on
+    }
+    if (ms_before) *ms_before = b0;
+    if (ms_after) *ms_after = a0;
     return LH_OK;
 }
 

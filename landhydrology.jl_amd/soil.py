@@ -22,6 +22,7 @@ columns (the reference has exactly one); every field is then [ncolumns, nelement
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Optional
 
@@ -629,6 +630,35 @@ def default_initial_conditions(model: SoilModel):
     return initialize_states(model, ic, FT(0.0))
 
 
+# Ensembles whose planes reach this size get their written states placed by
+# measurement (lh_tune_placement) the first time they are used; LH_PLACEMENT_TUNE=0
+# switches that off.
+PLACEMENT_TUNE_MIN_PLANE_BYTES = 32 << 20
+
+
+def _placement_tuning_wanted(model: SoilModel) -> bool:
+    d = model.domain
+    if os.environ.get("LH_PLACEMENT_TUNE", "1") == "0":
+        return False
+    return d.ncolumns * d.nelements * np.dtype(d.FT).itemsize >= PLACEMENT_TUNE_MIN_PLANE_BYTES
+
+
+def tune_placement(model: SoilModel, Y: "FieldVector", Ya=None, dY: Optional["FieldVector"] = None,
+                   max_candidates: int = 0, move_input: bool = True):
+    """Build extension (no counterpart in the reference): let the library choose, by
+    timing the real launch, where in HBM the state written by rhs! (dY given) or the
+    SSPRK33 stage state (dY=None) lives -- lh_tune_placement.  Returns the launch
+    time in ms before and after.  Results of later calls do not depend on it."""
+    be = model._backend()
+    ya = Ya.handle if isinstance(Ya, FieldVector) else None
+    be.set_bcs(model, 0.0)
+    b, a = C.c_float(), C.c_float()
+    F.check(F.lib().lh_tune_placement(be.ctx, Y.handle, ya, dY.handle if dY is not None else None,
+                                      int(max_candidates), F.LH_PLACE_MOVE_INPUT if move_input else 0,
+                                      C.byref(b), C.byref(a)), be.ctx)
+    return b.value, a.value
+
+
 def make_rhs(model: SoilModel):
     """make_rhs(model) -> rhs!(dY, Y, Ya, t) (right_hand_side.jl:33-44).  In place
     on dY, returns dY.  Everything numerical happens in lh_rhs on the GPU."""
@@ -643,6 +673,7 @@ def make_rhs(model: SoilModel):
     update_hy = make_update_aux(model.hydrology_model)
     L = F.lib()
     needs_aux = bool(_aux_mask(be.kind, model))
+    placed = set() if _placement_tuning_wanted(model) else None   # (Y, dY) pairs already placed
 
     def rhs(dY, Y, Ya, t):
         if needs_aux:
@@ -650,6 +681,10 @@ def make_rhs(model: SoilModel):
             update_hy(Ya, t)
         be.set_bcs(model, t)
         ya = Ya.handle if isinstance(Ya, FieldVector) else None
+        if placed is not None and (id(Y), id(dY)) not in placed:
+            placed.add((id(Y), id(dY)))
+            F.check(L.lh_tune_placement(be.ctx, Y.handle, ya, dY.handle, 0, F.LH_PLACE_MOVE_INPUT,
+                                        None, None), be.ctx)
         F.check(L.lh_rhs(be.ctx, float(t), Y.handle, ya, dY.handle), be.ctx)
         return dY
 
@@ -746,6 +781,10 @@ def _advance(sim: Simulation, nsteps: int):
                         vals[k, si, f, c] = float(v)
         bcv = np.ascontiguousarray(vals)
     be.set_bcs(model, it.t)
+    if not getattr(it, "_placed", False) and _placement_tuning_wanted(model):
+        it._placed = True
+        F.check(L.lh_tune_placement(be.ctx, it.u.handle, ya, None, 0, F.LH_PLACE_MOVE_INPUT, None, None),
+                be.ctx)
     F.check(L.lh_step_ssprk33(be.ctx, it.u.handle, ya, it.t, it.dt, nsteps,
                               bcv.ctypes.data_as(C.POINTER(C.c_double)) if bcv is not None
                               else None), be.ctx)
