@@ -38,6 +38,11 @@ for nm_full in names:
     g = pc.GpuModel(case)
     Y, Ya = g.prognostic_and_aux()
     dY = g.state(0)
+    if os.environ.get("TUNE"):                     # every model at its measured-best placement
+        tb, ta = C.c_float(), C.c_float()
+        F.check(g.L.lh_tune_placement(g.ctx, Y, Ya, dY if mode != "step" else None, int(os.environ["TUNE"]),
+                                      F.LH_PLACE_MOVE_INPUT, C.byref(tb), C.byref(ta)), g.ctx)
+        print(f"  tuned {nm_full}: {tb.value:.4f} -> {ta.value:.4f} ms", flush=True)
     models.append((nm_full, g, Y, Ya, dY))
 var = F.LH_VAR_VARTHETA_L if case.om.model != 1 else F.LH_VAR_RHOE_INT
 res = {nm: [] for nm in names}
