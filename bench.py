@@ -235,7 +235,7 @@ def main():
                    ("; RCCL min all-reduce of that value" if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kern_ms, "bytes_per_cell": bytes_per_cell,
+                     "kernel_ms": kern_ms, "kernel_reps": kreps, "bytes_per_cell": bytes_per_cell,
                      "algorithmic_bytes_per_launch": cells * bytes_per_cell},
         "placement_tuning": placement,
     }

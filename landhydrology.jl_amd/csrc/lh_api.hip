@@ -441,7 +441,8 @@ namespace {
 // plane_mask: which planes of the target move (the others stay where they are).
 template <typename RUN>
 int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_candidates,
-                      bool keep_contents, RUN&& run, float* ms_before, float* ms_after) {
+                      bool keep_contents, RUN&& run, float* ms_before, float* ms_after,
+                      float goal_ms = 0.0f) {
     struct Cand {
         void* plane[LH_NVARS];
         float ms;
@@ -451,7 +452,7 @@ int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_
     for (int i = 0; i < LH_NVARS; ++i) nplanes += (target->plane[i] != nullptr) && (plane_mask >> i & 1u);
     if (!nplanes) return LH_OK;
     int K = max_candidates > 0 ? max_candidates : 6;
-    if (K > 16) K = 16;
+    if (K > 64) K = 64;
     // every candidate stays allocated until the choice is made: keep well inside free memory
     size_t free_b = 0, total_b = 0;
     LH_HIP(c, hipMemGetInfo(&free_b, &total_b));
@@ -512,6 +513,12 @@ int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_
         }
         nc.ms = 0;
         cands.push_back(nc);
+        if (goal_ms > 0) { // a long search stops as soon as a candidate reaches the goal
+            for (int i = 0; i < LH_NVARS; ++i) target->plane[i] = nc.plane[i];
+            float ms = 0;
+            if ((rc = timed(ms))) break;
+            if (ms <= goal_ms) break;
+        }
     }
     // two interleaved passes, the minimum counts
     for (int pass = 0; pass < 2 && !rc; ++pass)
@@ -1055,15 +1062,17 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
             if (a1 < a0) a0 = a1; // b1 re-measures the placement a0 was measured on
         }
     // Most fresh memory is of one kind; if the tendency launch still sits below 70 % of the
-    // HBM peak by its algorithmic bytes, look once more, three times as far.
+    // HBM peak by its algorithmic bytes, look once more, eight times as far (stopping at the
+    // first candidate that gets there).
     if (dY && nwritten > 1) {
         int nread = 0;
         for (int i = 0; i < LH_NVARS; ++i) nread += Y->plane[i] != nullptr;
         const double bytes = double(nread + nwritten) * double(c->cfg.ncols) * double(c->cfg.nlev) * double(c->esize);
-        const int K = (max_candidates > 0 ? max_candidates : 6) * 3;
-        for (int i = 0; i < LH_NVARS && bytes / (double(a0) * 1e-3) < 0.70 * 8.0e12; ++i)
+        const int K = (max_candidates > 0 ? max_candidates : 6) * 8;
+        const float goal_ms = float(bytes / (0.70 * 8.0e12) * 1e3);
+        for (int i = 0; i < LH_NVARS && a0 > goal_ms; ++i)
             if (written->plane[i]) {
-                if ((rc = tune_state_planes(c, written, 1u << i, K, false, run, &b1, &a1))) return rc;
+                if ((rc = tune_state_planes(c, written, 1u << i, K, false, run, &b1, &a1, goal_ms))) return rc;
                 if (a1 < a0) a0 = a1;
             }
     }

@@ -37,8 +37,24 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_grbm"):
             print(f"    -> HBM read bytes/launch (bytes; FETCH_SIZE KiB x 1024 x 2, the gfx950 wide-read correction): {2*1024*sum(v)/len(v):.6g}")
         if k == "WRITE_SIZE":
             print(f"    -> HBM write bytes/launch (bytes; WRITE_SIZE KiB x 1024): {1024*sum(v)/len(v):.6g}")
+bench_line = None
 for f in glob.glob(os.path.join(d, "bench_trace.log")):
     for line in open(f):
         if line.startswith("{"):
-            j = json.loads(line)
-            print("== bench line (profiled run):", json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline")}))
+            bench_line = json.loads(line)
+# The run starts with the placement trials of lh_tune_placement (the same kernel on other
+# plane slots, some of them slow) and ends with the back-to-back block bench.py times with
+# HIP events (roofline.kernel_ms over roofline.kernel_reps launches): compare like with like.
+disp = [r for r in rows("trace/**/*kernel_trace.csv") if r.get("Kernel_Name") == dom]
+if disp and bench_line:
+    disp.sort(key=lambda r: int(r["Start_Timestamp"]))
+    n = int(bench_line["roofline"].get("kernel_reps", 0)) or len(disp)
+    last = disp[-n:]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
+    print(f"== dominant kernel, last {len(last)} dispatches (the HIP-event timed block of bench.py): "
+          f"avg_ns={sum(dur) / len(dur):.0f} min_ns={min(dur)} max_ns={max(dur)}")
+    alld = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in disp]
+    print(f"   all {len(alld)} dispatches incl. placement trials and warm-up: avg_ns={sum(alld) / len(alld):.0f}")
+if bench_line:
+    print("== bench line (profiled run):", json.dumps({k: bench_line.get(k) for k in
+                                                        ("value", "ms_per_step", "roofline", "placement_tuning")}))
