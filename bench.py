@@ -68,6 +68,33 @@ def build_case(workload, ncols, col_offset):
     return pc.make_case(name, ncols=ncols, col_offset=col_offset)
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU
+    quota when there is one (a GPU box hands out a 16-core share per GPU of a 128-core
+    host; 128 OpenMP threads on that share just time the scheduler)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                tok = fh.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(int(tok[0]) / int(tok[1]) + 0.5)))
+            else:
+                q = int(tok[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, int(q / int(fh.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("LH_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_baseline(case, seconds):
     """The oracle (kind 'port': a scalar C restatement of the reference's Julia
     path; the reference itself cannot run here) timed on a bounded sample of the
@@ -75,8 +102,8 @@ def cpu_baseline(case, seconds):
     import dataclasses
     import oracle_py as O
     import parity_cases as pc
-    cores = os.cpu_count() or 1
-    threads = min(cores, O.max_threads())
+    cores = _usable_cores()
+    threads = max(1, min(cores, O.max_threads()))
     n = case.om.nlev
     sample = min(case.ncols, 20000)
     sl = lambda a: None if a is None else np.ascontiguousarray(a[:sample])

@@ -237,6 +237,24 @@ function step_ssprk33_device_dt!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt_
     return Y
 end
 
+"""
+    tune_placement!(ens, Y, Ya, dY = nothing; max_candidates = 0, move_input = true)
+
+Let the library place the state written by `rhs!` (`dY` given) or the SSPRK33 stage state
+(`dY === nothing`) in HBM by timing the real launch (lh_tune_placement).  Returns
+`(ms_before, ms_after)`.  Worth one call per (Y, dY) pair for ensembles with planes >= 32 MiB.
+"""
+function tune_placement!(ens::ColumnEnsemble, Y::DeviceState, Ya, dY = nothing; max_candidates = 0, move_input = true)
+    set_bcs!(ens, 0.0)
+    b, a = Ref{Cfloat}(0), Ref{Cfloat}(0)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_tune_placement, lib), Cint,
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, UInt32, Ptr{Cfloat}, Ptr{Cfloat}),
+                         ens.ctx, Y.handle, ya, dY === nothing ? C_NULL : dY.handle, max_candidates,
+                         move_input ? UInt32(1) : UInt32(0), b, a))
+    return b[], a[]
+end
+
 function stable_dt(ens::ColumnEnsemble, Y::DeviceState, Ya = nothing; courant = 0.5)
     out = Ref{Float64}(0.0)
     ya = Ya === nothing ? C_NULL : Ya.handle
