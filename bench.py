@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-placement-tune", action="store_true",
                     help="skip lh_tune_placement (measure the first placement the allocator gives)")
     ap.add_argument("--ncols", type=int, default=1_000_000, help="columns per GPU")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -57,6 +57,12 @@ WORKLOADS = {
     "c3": ("c3_coupled_f32", 24.0, "f32"),
     "c4": ("c4_richards_f64_128", 32.0, "f64"),
     "c5": ("c5_percol_f64", 32.5, "f64"),
+    # SURVEY 8(f)-3 at scale: ice lenses + saturated zones + both conductivity factors, Dirichlet
+    # top / free-drainage bottom (coupled, 48 levels); viscosity factor with prescribed T (Richards,
+    # 50 levels: one more plane read)
+    "f3c32": ("mixed_smooth_f32", 24.0, "f32"),
+    "f3c64": ("mixed_smooth_f64", 48.0, "f64"),
+    "f3v64": ("richards_viscosity_f64", 40.0, "f64"),
 }
 
 
@@ -254,12 +260,13 @@ def main():
         "dtype": WORKLOADS[a.workload][2],
         "data": "synthetic",
         "config": {"workload": f"{a.workload.upper()}: {a.ncols} independent {nlev}-layer "
-                               f"{'coupled water+heat' if a.workload == 'c3' else 'Richards'} columns per GPU "
+                               f"{'coupled water+heat' if case.om.model == 2 else 'Richards'} columns per GPU "
                                f"({WORKLOADS[a.workload][2]}), one lh_rhs launch per step",
                    "columns_per_gpu": a.ncols, "levels": nlev,
                    "partition": (f"block over {world} rank(s); " if world > 1 else "single GPU; ") +
                    "every 3rd eval also yields the rank's stable dt (fused)" +
-                   ("; RCCL min all-reduce of that value" if world > 1 else "")},
+                   (f"; {'RCCL' if a.backend == 'nccl' else a.backend} min all-reduce of that value"
+                    if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "kernel_reps": kreps, "bytes_per_cell": bytes_per_cell,

@@ -177,15 +177,15 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         }
     }
     if (FACTORS) {
-        FT visc = FT(1), imp = FT(1);
-        if (P.viscosity_kind) visc = mm.exp(P.gamma * (T - P.T_ref_visc));
+        // exp(gamma (T - T_ref)) 10^(-Omega f_i) as ONE 2^(.): the two exponents add
+        FT ex = FT(0);
+        if (P.viscosity_kind) ex = (P.gamma * (T - P.T_ref_visc)) * FT(1.4426950408889634);
         if (P.impedance_kind) {
-            FT tl = liquid_fraction(vl, nu_eff);
-            FT f_i = ti / (tl + ti);
-            // 10^(-Omega f_i) = 2^(-Omega f_i log2 10) on the production exp2
-            imp = mm.exp2((-P.Omega * f_i) * FT(3.3219280948873623));
+            const FT tl = liquid_fraction(vl, nu_eff);
+            const FT f_i = ti * mm.rcp(tl + ti); // 0/0 = NaN as in the reference
+            ex = fma_ft(-P.Omega * f_i, FT(3.3219280948873623), ex);
         }
-        K = K * visc * imp;
+        K = K * mm.exp2(ex);
     }
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
@@ -215,9 +215,52 @@ __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>&
 // volumetric_heat_capacity (:65-79), temperature_from_rhoe_int (:42-53),
 // relative_saturation (:139-142), kersten_number (:152-174),
 // saturated_thermal_conductivity (:114-128), thermal_conductivity (:185-188).
+// The production form of kappa: Kersten number and saturated conductivity in the
+// log2 domain.  One log2(S_r) serves the frozen and the unfrozen exponent (a wave
+// with both kinds of lanes no longer evaluates two pows), and
+// kappa_su^(tl/tw) kappa_sf^(ti/tw) = 2^((tl log2 kappa_su + ti log2 kappa_sf)/tw)
+// is one exp2 instead of two pows.
+template <typename FT, typename M>
+__device__ __forceinline__ FT kappa_closure_log(const M& mm, const DevParams<FT>& P,
+                                                const ColC<FT>& c, FT vl, FT ti) {
+    constexpr FT SC = FT(M::EXP2_SCALE);
+    const FT nu_eff = c.nu - ti;
+    const FT tl = liquid_fraction(vl, nu_eff);
+    const FT tw = tl + ti;
+    const FT S_r = tw * c.inv_nu;
+    const bool unfrozen = ti < Limits<FT>::eps();
+    // S_r^e: 0 for S_r == 0 (e > 0), NaN for S_r < 0 or NaN (DomainError in the reference).
+    // The hardware Float32 log/exp give exactly that (log2 0 = -inf, 2^-inf = 0); the table
+    // log2 of the Float64 policy needs a positive normal argument.
+    const FT e_sel = unfrozen ? P.kersten_exp_unfrozen * SC : P.kersten_exp_frozen * SC;
+    FT K_e;
+    if constexpr (M::uses_tables) {
+        K_e = mm.exp2_scaled(mm.log2(S_r > FT(0) ? S_r : FT(1)) * e_sel);
+        K_e = (S_r > FT(0)) ? K_e : ((S_r == FT(0)) ? FT(0) : FT(NAN));
+    } else {
+        K_e = mm.exp2_scaled(mm.log2(S_r) * e_sel);
+    }
+    if (unfrozen) {
+        const FT e = mm.exp(-P.b * S_r);
+        const FT a = mm.pow_neg3(FT(1) + e);    // (1 + exp(-b S_r))^(-3)
+        const FT h = (FT(1) - S_r) * FT(0.5);
+        const FT d = a - h * h * h;             // ((1 - S_r)/2)^3
+        // (.)^(1 - nu_om): the exponent is exactly 1 for soils without organic matter
+        K_e = K_e * ((P.one_minus_om == FT(1)) ? d : mm.pow(d, P.one_minus_om));
+    }
+    FT k_sat = P.kappa_sat_unfrozen;            // tl/tw == 1 exactly when ti == 0
+    if (ti != FT(0)) {
+        const FT itw = mm.rcp(tw);
+        k_sat = mm.exp2_scaled(((tl * (P.l2_kappa_sat_unfrozen * SC) + ti * (P.l2_kappa_sat_frozen * SC)) * itw));
+    }
+    k_sat = (tw < Limits<FT>::eps()) ? FT(0) : k_sat;
+    return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
+}
+
 template <typename FT, typename M>
 __device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
                                             const ColC<FT>& c, FT vl, FT ti) {
+    if constexpr (M::is_production) return kappa_closure_log<FT, M>(mm, P, c, vl, ti);
     const FT nu_eff = c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
     const FT tw = tl + ti;
