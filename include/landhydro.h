@@ -184,6 +184,10 @@ int lh_upload(lh_ctx*, lh_state*, int32_t var, const void* host, int64_t lev_str
               int64_t col_stride);
 int lh_download(lh_ctx*, const lh_state*, int32_t var, void* host, int64_t lev_stride,
                 int64_t col_stride);
+/* one level of one variable, FT[ncols] (level 0 = bottom cell, nlev-1 = top cell):
+ * what interior_values(X, face, cs) hands to a host-evaluated boundary condition
+ * (boundary_conditions.jl:174-186, 516-533) -- ncols values instead of a plane */
+int lh_download_level(lh_ctx*, const lh_state*, int32_t var, int32_t level, void* host);
 int lh_state_fill(lh_ctx*, lh_state*, int32_t var, double value);
 int lh_state_copy(lh_ctx*, lh_state* dst, const lh_state* src);
 /* zero-copy access: device pointer of a plane and its element strides

@@ -73,6 +73,7 @@ SIGNATURES = {
     "lh_state_destroy": (C.c_int, [_P, _P]),
     "lh_upload": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lh_download": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, C.c_int64]),
+    "lh_download_level": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "lh_state_fill": (C.c_int, [_P, _P, C.c_int32, C.c_double]),
     "lh_state_copy": (C.c_int, [_P, _P, _P]),
     "lh_state_device_ptr": (C.c_int, [_P, _P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64),

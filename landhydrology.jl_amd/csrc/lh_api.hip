@@ -826,6 +826,19 @@ int lh_download(lh_ctx* c, const lh_state* s, int32_t var, void* host, int64_t l
     return transfer(c, const_cast<lh_state*>(s), var, host, ls, cs, false);
 }
 
+int lh_download_level(lh_ctx* c, const lh_state* s, int32_t var, int32_t level, void* host) {
+    if (!c || !s || !host) return fail(c, LH_EINVAL, "lh_download_level: NULL argument");
+    if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    if (level < 0 || level >= c->cfg.nlev) return fail(c, LH_EINVAL, "lh_download_level: level %d outside [0, %d)", level, c->cfg.nlev);
+    (void)hipSetDevice(c->device);
+    // a level of a plane is one contiguous row of ncols elements
+    const char* row = static_cast<const char*>(s->plane[var]) + size_t(level) * size_t(c->stride) * c->esize;
+    LH_HIP(c, hipMemcpyAsync(host, row, size_t(c->cfg.ncols) * c->esize, hipMemcpyDeviceToHost, c->stream));
+    LH_HIP(c, hipStreamSynchronize(c->stream));
+    return LH_OK;
+}
+
 int lh_state_fill(lh_ctx* c, lh_state* s, int32_t var, double value) {
     if (!c || !s) return fail(c, LH_EINVAL, "lh_state_fill: NULL argument");
     if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");

@@ -186,6 +186,13 @@ function upload(ens::ColumnEnsemble; fields...)
     end
     return st
 end
+"interior_values(X, face, cs) for every column: one level of one variable (1 = bottom, nelements = top)"
+function download_level(st::DeviceState, var::Symbol, level::Integer, ::Type{FT}) where {FT}
+    out = Vector{FT}(undef, st.ens.ncolumns)
+    check(st.ens.ctx, ccall((:lh_download_level, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}),
+                            st.ens.ctx, st.handle, LH_VAR[var], level - 1, out))
+    return out
+end
 download(st::DeviceState, var::Symbol, ::Type{FT}) where {FT} =
     download!(Matrix{FT}(undef, st.ens.model.domain.nelements, st.ens.ncolumns), st, var)
 

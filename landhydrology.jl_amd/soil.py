@@ -332,6 +332,16 @@ class FieldVector:
                                     d.nelements), self._be.ctx)
         return out
 
+    def get_level(self, name, level) -> np.ndarray:
+        """One level of one variable for every column ([ncolumns]; level -1 = the top
+        cell): interior_values(X, :top, cs) of a host-evaluated boundary condition."""
+        d = self.model.domain
+        lev = int(level) % d.nelements if -d.nelements <= int(level) < d.nelements else int(level)
+        out = np.empty(d.ncolumns, dtype=d.FT)
+        F.check(F.lib().lh_download_level(self._be.ctx, self.handle, _VAR[name], lev, out.ctypes.data),
+                self._be.ctx)
+        return out
+
     def set(self, name, value):
         d = self.model.domain
         a = np.asarray(value, dtype=d.FT)

@@ -187,6 +187,43 @@ def test_ensemble_extension_and_per_column_parameters(lh):
     pc.assert_tendencies_close(case, {"vl": dY.soil.ϑ_l, "ti": dY.soil.θ_i}, want, 4.0)
 
 
+def test_host_evaluated_top_flux_from_interior_values(lh):
+    """The route a host-evaluated top boundary condition takes (the reference's
+    PrescribedAtmosForcing computes its fluxes from interior_values(X, :top, cs),
+    boundary_conditions.jl:516-533): fetch the top-cell state of every column
+    (lh_download_level), form a per-column flux on the host, hand it back as a
+    per-column VerticalFlux.  Checked against the oracle with the same fluxes."""
+    FT = np.float64
+    case = pc.make_case("c5_percol_f64", ncols=300)
+    pcol = case.om.percol
+    hm = lh.vanGenuchten(FT, n=pcol["vg_n"], α=pcol["vg_alpha"], Ksat=pcol["vg_Ksat"],
+                         θr=pcol["vg_theta_r"])
+    domain = lh.Column(FT, zlim=(-2.56, 0.0), nelements=128, ncolumns=300)
+    top = lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0))
+    bc = lh.SoilColumnBC(top=top, bottom=lh.SoilComponentBC(hydrology=lh.FreeDrainage()))
+    model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                         hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                         boundary_conditions=bc, soil_param_set=lh.SoilParams(FT, ν=pcol["nu"]),
+                         earth_param_set=lh.EarthParameterSet())
+    Y, Ya = lh.initialize_states(model, lambda z, m: {"ϑ_l": case.vl, "θ_i": case.ti}, 0.0)
+    top_vl = Y.get_level("ϑ_l", -1)
+    np.testing.assert_array_equal(top_vl, case.vl[:, -1])
+    np.testing.assert_array_equal(Y.get_level("ϑ_l", 0), case.vl[:, 0])
+    np.testing.assert_array_equal(Y.get_level("θ_i", 5), case.ti[:, 5])
+    with pytest.raises(lh.LandHydroError):
+        Y.get_level("ϑ_l", 128)
+    # an evaporation-like flux of the top-cell moisture, per column (positive = upward)
+    evap = 1e-7 * (top_vl - pcol["vg_theta_r"]) / (pcol["nu"] - pcol["vg_theta_r"])
+    top.hydrology = lh.VerticalFlux(evap)
+    dY = Y.similar()
+    lh.make_rhs(model)(dY, Y, Ya, 0.0)
+    import dataclasses
+    O = pc.O
+    om = dataclasses.replace(case.om, percol_bc={(O.FACE_TOP, O.COMP_HYDROLOGY): evap})
+    want = pc.run_oracle_rhs(dataclasses.replace(case, om=om))
+    pc.assert_tendencies_close(case, {"vl": dY.soil.ϑ_l, "ti": dY.soil.θ_i}, want, 4.0)
+
+
 def test_error_behaviour(lh):
     FT = np.float64
     domain = lh.Column(FT, zlim=(-1.0, 0.0), nelements=8)
