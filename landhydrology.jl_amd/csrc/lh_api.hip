@@ -212,6 +212,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.status = c->d_status;
     P.math_tab = c->d_math_tab;
     P.dt_out = nullptr;
+    P.xcd_remap = 0;
     return P;
 }
 
@@ -220,6 +221,7 @@ void parse_tune(Tune& tu, const char* t) {
     tu = Tune();
     int v;
     const char* q;
+    if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
@@ -304,6 +306,7 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
            void* dt_out = nullptr) {
     DevParams<FT> P = make_params<FT>(c);
     P.dt_out = dt_out;
+    P.xcd_remap = c->tune.xcd;
     if (bc_override)
         for (int f = 0; f < 2; ++f)
             for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);

@@ -172,7 +172,15 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
 
-    const int64_t col0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * CPL;
+    // Workgroups are dealt round-robin to the 8 XCDs.  With xcd_remap, workgroup b handles
+    // column block (b % 8) * (nblocks / 8) + b / 8: each XCD streams one contiguous eighth of
+    // every plane row instead of every eighth 2-KiB piece.
+    unsigned blk = blockIdx.x;
+    if (P.xcd_remap) {
+        const unsigned per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const int64_t col0 = (int64_t(blk) * blockDim.x + threadIdx.x) * CPL;
     if (col0 >= P.ncols) return;
     const int64_t stride = P.stride;
     // 32-bit BYTE offset of this lane inside a plane row (lh_create bounds a row to < 4 GiB)

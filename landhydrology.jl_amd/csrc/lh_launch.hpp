@@ -19,6 +19,7 @@ struct Tune {
     int pad = -1; // plane address stagger in bytes (state allocation)
     int arena = 0; // plane slots per device allocation (0 = default)
     int rowpad = -1; // extra elements per plane row (-1 = library default)
+    int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
 };
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)
