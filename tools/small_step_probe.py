@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Launch-bound regime: time lh_step_ssprk33 for small ensembles (steps/s)."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import torch  # noqa: F401
+import bench
+import parity_cases as pc
+
+for wl, ncols in (("c2", 1), ("c2", 1024), ("c3", 1), ("c3", 16384), ("c2", 65536)):
+    case = bench.build_case(wl, ncols, 0)
+    g = pc.GpuModel(case)
+    F = g.F
+    Y, Ya = g.prognostic_and_aux()
+    nsteps = 3000
+    F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, 1e-6, 200, None), g.ctx)
+    F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+    t0 = time.perf_counter()
+    F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, 1e-6, nsteps, None), g.ctx)
+    F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+    el = time.perf_counter() - t0
+    print(f"{wl} ncols={ncols:6d}: {el / nsteps * 1e6:8.2f} us per step ({el / nsteps / 3 * 1e6:.2f} us per stage launch)", flush=True)
+    g.close()
