@@ -71,6 +71,7 @@ struct lh_ctx {
     void* d_dt = nullptr;              // FT scratch for lh_stable_dt
     double* d_math_tab = nullptr;      // log2/exp2 tables of MathFast<double>
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
+    lh_state* scratch_u2 = nullptr;    // second stage state (level-segmented launches cannot update U1 in place)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int math = MATH_FAST;
     Tune tune;
@@ -122,6 +123,24 @@ template <> double host_pow<double>(double x, double y) { return std::pow(x, y);
 template <> float host_pow<float>(float x, float y) { return powf(x, y); }
 
 // Build the kernel argument, rounding to FT where the Julia constructors do.
+// Levels per segment of the level-segmented launch (rhs_kernel, CFG::SEG), 0 = one lane
+// marches the whole column.  Below ~2.6e5 lanes the launch time is the latency of one
+// lane's march, so the column is cut into as many segments as it takes to fill the chip,
+// each at least 4 levels long (every segment evaluates two extra cells).
+int segment_length(const lh_ctx* c) {
+    const int nlev = c->cfg.nlev;
+    if (c->tune.seg < 0) return 0;
+    if (c->tune.seg > 0) return c->tune.seg < nlev ? c->tune.seg : 0;
+    const int64_t lanes = c->cfg.dtype == LH_F64 ? c->cfg.ncols : (c->cfg.ncols + 1) / 2;
+    const int64_t target = 262144; // 256 CUs x 4 SIMDs x 64 lanes x 4 waves
+    if (lanes * 2 > target || nlev < 16) return 0;
+    int64_t nseg = (target + lanes - 1) / lanes;
+    if (nseg > nlev / 4) nseg = nlev / 4;
+    if (nseg < 2) return 0;
+    const int len = int((nlev + nseg - 1) / nseg);
+    return len < nlev ? len : 0;
+}
+
 template <typename FT>
 DevParams<FT> make_params(const lh_ctx* c) {
     const HostParams& h = c->hp;
@@ -213,6 +232,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.math_tab = c->d_math_tab;
     P.dt_out = nullptr;
     P.xcd_remap = 0;
+    P.seg_len = segment_length(c);
     return P;
 }
 
@@ -221,6 +241,7 @@ void parse_tune(Tune& tu, const char* t) {
     tu = Tune();
     int v;
     const char* q;
+    if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
@@ -404,6 +425,19 @@ void state_free(lh_ctx* c, lh_state* s) {
             break;
         }
     delete s;
+}
+
+// A level-segmented stage reads cells its neighbour segments write: it needs a target
+// other than its input, i.e. a second stage state.
+int second_stage_state(lh_ctx* c, lh_state** U2) {
+    if (segment_length(c) <= 0) return LH_OK; // in place
+    if (!c->scratch_u2) {
+        const uint32_t pm = prognostic_mask(c->cfg.model);
+        int rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u2);
+        if (rc) return rc;
+    }
+    *U2 = c->scratch_u2;
+    return LH_OK;
 }
 
 int upload_percol(lh_ctx* c, void** slot, const double* host) {
@@ -777,6 +811,7 @@ int lh_state_destroy(lh_ctx* c, lh_state* s) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch_u1 == s) c->scratch_u1 = nullptr;
+    if (c->scratch_u2 == s) c->scratch_u2 = nullptr;
     state_free(c, s);
     return LH_OK;
 }
@@ -946,12 +981,15 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     // the stage state carries no theta_i plane: the fused stages read theta_i from Y
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
+    lh_state* U2 = U1;
+    if ((rc = second_stage_state(c, &U2))) return rc;
     for (int64_t s = 0; s < nsteps; ++s) {
         for (int stage = 0; stage < 3; ++stage) {
             const double* ov = bcv ? bcv + (s * 3 + stage) * 4 : nullptr;
-            // stage 1: U1 = Y + dt f(Y); 2: U1 = (3Y + U1 + dt f(U1))/4; 3: Y = (Y + 2U1 + 2dt f(U1))/3
-            const lh_state* in = stage == 0 ? Y : U1;
-            lh_state* out = stage == 2 ? Y : U1;
+            // stage 1: U1 = Y + dt f(Y); 2: U2 = (3Y + U1 + dt f(U1))/4; 3: Y = (Y + 2U2 + 2dt f(U2))/3
+            // (U2 is U1 itself unless the launch is level-segmented)
+            const lh_state* in = stage == 0 ? Y : (stage == 1 ? U1 : U2);
+            lh_state* out = stage == 2 ? Y : (stage == 1 ? U2 : U1);
             rc = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, dt, stage + 1, ov)
                                         : do_rhs<float>(c, in, Ya, Y, out, dt, stage + 1, ov);
             if (rc) return rc;
@@ -972,10 +1010,12 @@ int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double
     (void)hipSetDevice(c->device);
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
+    lh_state* U2 = U1;
+    if ((rc = second_stage_state(c, &U2))) return rc;
     for (int stage = 0; stage < 3; ++stage) {
         const double* ov = bcv ? bcv + stage * 4 : nullptr;
-        const lh_state* in = stage == 0 ? Y : U1;
-        lh_state* out = stage == 2 ? Y : U1;
+        const lh_state* in = stage == 0 ? Y : (stage == 1 ? U1 : U2);
+        lh_state* out = stage == 2 ? Y : (stage == 1 ? U2 : U1);
         rc = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, 0.0, stage + 1, ov, dt_device_ft)
                                     : do_rhs<float>(c, in, Ya, Y, out, 0.0, stage + 1, ov, dt_device_ft);
         if (rc) return rc;
@@ -1050,6 +1090,11 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
     (void)hipSetDevice(c->device);
     const bool f64 = c->cfg.dtype == LH_F64;
     lh_state* written = dY;
+    if (!dY && segment_length(c) > 0) { // small ensemble (cache-resident, two stage states): nothing to place
+        if (ms_before) *ms_before = 0;
+        if (ms_after) *ms_after = 0;
+        return LH_OK;
+    }
     if (!dY) { // the stage state of the fused SSPRK33 stepper
         if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
         written = c->scratch_u1;

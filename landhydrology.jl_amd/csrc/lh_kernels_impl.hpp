@@ -88,10 +88,11 @@ __device__ __forceinline__ void bstore(FT* row, unsigned row_bytes, unsigned lan
 
 // launch shape of the column kernel: columns per lane, levels kept in flight
 // ahead of the one being computed, nontemporal global access
-template <int CPL_, int PF_, bool NT_>
+// SEG: level-segmented launch for small ensembles (see rhs_kernel)
+template <int CPL_, int PF_, bool NT_, bool SEG_>
 struct KCfg {
     static constexpr int CPL = CPL_, PF = PF_;
-    static constexpr bool NT = NT_;
+    static constexpr bool NT = NT_, SEG = SEG_;
 };
 
 // Stage the log2/exp2 tables of MathFast<double> in LDS (5 KiB per workgroup);
@@ -142,6 +143,15 @@ __device__ __forceinline__ bool finite(FT x) {
 // tendency is identically zero (right_hand_side.jl:182, :359), so every stage
 // value of theta_i equals Y's.
 //
+// CFG::SEG (small ensembles): a column no longer belongs to one lane.  With fewer
+// columns than the chip has lanes the launch is bound by the LATENCY of one lane's
+// bottom-to-top march (35 us for 64 Float64 levels, whatever the column count up to
+// ~1e5), so blockIdx.y splits every column into segments of P.seg_len levels.  A lane
+// computes the closures of its own cells plus the one cell below and the one above its
+// segment (the face fluxes at the segment ends are evaluated by both neighbours from
+// the same inputs in the same order: bitwise equal, conservation is untouched) and
+// emits only its own cells.  Results are bitwise those of the unsegmented launch.
+//
 // Addressing: a uniform row pointer per plane (SGPRs, advanced by `stride` per
 // level) plus one 32-bit lane offset, so the loop carries no vector address
 // arithmetic.  The level coordinate z_i comes from LDS (staged once per block):
@@ -183,6 +193,12 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     const int64_t col0 = (int64_t(blk) * blockDim.x + threadIdx.x) * CPL;
     if (col0 >= P.ncols) return;
     const int64_t stride = P.stride;
+    // cells this lane emits: [i_lo, i_hi); cells whose closures it evaluates: [i_first, i_end)
+    constexpr bool SEG = CFG::SEG;
+    const int i_lo = SEG ? int(blockIdx.y) * P.seg_len : 0;
+    const int i_hi = SEG ? (i_lo + P.seg_len < n ? i_lo + P.seg_len : n) : n;
+    const int i_first = (SEG && i_lo > 0) ? i_lo - 1 : 0;
+    const int i_end = (SEG && i_hi < n) ? i_hi + 1 : n;
     // 32-bit BYTE offset of this lane inside a plane row (lh_create bounds a row to < 4 GiB)
     const unsigned lane_byte = (unsigned)col0 * (unsigned)sizeof(FT);
     const unsigned row_bytes = (unsigned)(stride * (int64_t)sizeof(FT));
@@ -198,16 +214,17 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 
     // uniform row pointers (level 0); HEAT reads the prescribed water fields from
     // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
-    const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]);
-    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1]));
-    const FT* r_re = HEAT ? IN.v[2] : nullptr;
+    const int64_t in0 = SEG ? stride * i_first : 0, out0 = SEG ? stride * i_lo : 0;
+    const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + in0;
+    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1])) + in0;
+    const FT* r_re = HEAT ? IN.v[2] + in0 : nullptr;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
-    const FT* r_Ta = need_Taux ? AUX.v[3] : nullptr;
-    const FT* b_vl = ((MODE == 2 || MODE == 3) && WATER) ? BASE.v[0] : nullptr;
-    const FT* b_re = ((MODE == 2 || MODE == 3) && HEAT) ? BASE.v[2] : nullptr;
-    FT* o_vl = WATER ? OUT.v[0] : nullptr;
-    FT* o_ti = (WATER && TEND) ? OUT.v[1] : nullptr;
-    FT* o_re = HEAT ? OUT.v[2] : nullptr;
+    const FT* r_Ta = need_Taux ? AUX.v[3] + in0 : nullptr;
+    const FT* b_vl = ((MODE == 2 || MODE == 3) && WATER) ? BASE.v[0] + out0 : nullptr;
+    const FT* b_re = ((MODE == 2 || MODE == 3) && HEAT) ? BASE.v[2] + out0 : nullptr;
+    FT* o_vl = WATER ? OUT.v[0] + out0 : nullptr;
+    FT* o_ti = (WATER && TEND) ? OUT.v[1] + out0 : nullptr;
+    FT* o_re = HEAT ? OUT.v[2] + out0 : nullptr;
 
     ColC<FT> c[CPL];
     int64_t colj[CPL]; // column index clamped into [0, ncols): pad lanes reuse the last column
@@ -253,7 +270,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             vl_n[k][j] = ti_n[k][j] = re_n[k][j] = FT(0);
             Ta_n[k][j] = FT(288);
         }
-        if (k < n) fetch(k);
+        if (i_first + k < i_end) fetch(k);
     }
 
     // emit the result of the cell the OUT/BASE row pointers address
@@ -313,11 +330,11 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
     };
 
-    for (int i0 = 0; i0 < n; i0 += PF) {
+    for (int i0 = i_first; i0 < i_end; i0 += PF) {
 #pragma unroll
       for (int k = 0; k < PF; ++k) {
         const int i = i0 + k;
-        if (PF > 1 && i >= n) break;
+        if (PF > 1 && i >= i_end) break;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             vl[j] = vl_n[k][j];
@@ -325,7 +342,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             re[j] = re_n[k][j];
             Ta[j] = Ta_n[k][j];
         }
-        if (i + PF < n) fetch(k); // keep PF levels in flight ahead of the one computed
+        if (i + PF < i_end) fetch(k); // keep PF levels in flight ahead of the one computed
         const FT z = s_zc[i];
         FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], dpsi[CPL], rcs[CPL];
 #pragma unroll
@@ -350,7 +367,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     D = K[j] * dpsi[j];
                     if (HEAT) D = fmax_ft(D, kap[j] * mm.rcp(rcs[j]));
                 }
-                if (i > 0) {
+                if (i > i_first) {
                     D = fmax_ft(D, (K_p[j] + K[j]) * FT(0.5) * fmax_ft(dpsi_p[j], dpsi[j]));
                     if (HEAT) D = fmax_ft(D, (kap_p[j] + kap[j]) * FT(0.5) * mm.rcp(fmin_ft(rcs_p[j], rcs[j])));
                 }
@@ -368,7 +385,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0)) * mm.rcp(rcs[j]));
                 }
             }
-        } else {
+        } else if (!SEG || i > i_first) { // (the cell below a segment only primes the *_p values)
             FT Fw[CPL], Fe[CPL];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -384,7 +401,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                     if (WATER) Fe[j] = Fe[j] - ((E_p[j] + E[j]) * FT(0.5)) * gh;
                 }
             }
-            emit(Fw, Fe, vl_p, re_p);
+            if (!SEG || i > i_lo) emit(Fw, Fe, vl_p, re_p); // cell i-1 belongs to this segment
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 Fw_lo[j] = Fw[j];
@@ -408,7 +425,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
       }
     }
-    {
+    if (!SEG || i_hi == n) { // the top face of the column
         FT Fw[CPL], Fe[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -653,6 +670,7 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
                             int mode, int block, hipStream_t s) {
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
+    if (CFG::SEG) g.y = (unsigned)((P.nlev + P.seg_len - 1) / P.seg_len);
     // dynamic LDS: z_i, plus one word per thread for the mode-4 reduction
     const unsigned dyn = (unsigned)((((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15) +
                                     (mode == 4 ? (size_t)block * sizeof(FT) : 0));
@@ -701,9 +719,12 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     const bool nt = tune.nt >= 0 ? tune.nt != 0 : touched > 192.0 * 1024 * 1024;
     using CFGN = KCfg<CFG::CPL, CFG::PF, true>;
     using CFGP = KCfg<CFG::CPL, CFG::PF, false>;
+    using CFGS = KCfg<CFG::CPL, CFG::PF, false, true>; // level-segmented (small ensembles: cache-resident)
+    const bool seg = M::is_production && P.seg_len > 0 && P.seg_len < P.nlev;
 #define LH_GO(F, PC)                                                                                  \
     do {                                                                                              \
-        if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+        if (seg) launch_rhs_mode<FT, MODEL, F, PC, CFGS, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+        else if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
         else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s);   \
     } while (0)
     if (factors) {

@@ -6,7 +6,7 @@ namespace lh {
 
 enum { MATH_FAST = 0, MATH_LIBM = 1 };
 
-template <int CPL_, int PF_, bool NT_> struct KCfg;
+template <int CPL_, int PF_, bool NT_, bool SEG_ = false> struct KCfg;
 // production launch shape per working type (chosen by measurement)
 template <typename FT> struct DefaultCfg;
 template <> struct DefaultCfg<double> { using type = KCfg<1, 2, false>; }; // 2 levels in flight: -2..3 % (profiles/round1_tune_prefetch.txt)
@@ -19,6 +19,7 @@ struct Tune {
     int pad = -1; // plane address stagger in bytes (state allocation)
     int arena = 0; // plane slots per device allocation (0 = default)
     int rowpad = -1; // extra elements per plane row (-1 = library default)
+    int seg = 0;     // levels per segment of the level-segmented launch (0 = automatic, -1 = never)
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
 };
 

@@ -1,0 +1,78 @@
+"""Level-segmented launches (small ensembles: blockIdx.y cuts every column into
+segments, rhs_kernel CFG::SEG) must be BITWISE the unsegmented launch: the same
+closures of the same cells, the shared faces evaluated twice from the same inputs.
+
+Through the C ABI, for every model / BC / factor combination of the parity cases:
+tendency, fused tendency + stable dt, and the fused SSPRK33 stepper, with the
+unsegmented launch (LH_TUNE seg=-1) as the reference and segment lengths that
+divide the column, do not divide it, are 1, and the automatic choice.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+O = pc.O
+
+CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c3_coupled_f32", "c3_coupled_f64",
+         "c5_percol_f64", "heat_dirichlet_f64", "heat_dirichlet_f32", "mixed_factors_f64",
+         "mixed_smooth_f32", "richards_viscosity_f64"]
+SEGS = [b"seg=8", b"seg=5", b"seg=1", b"seg=0"]          # seg=0: the library's own choice
+
+
+def _fields(g, st, case):
+    F, m = g.F, case.om.model
+    out = {}
+    if m != O.MODEL_HEAT:
+        out["vl"] = g.download(st, F.LH_VAR_VARTHETA_L)
+        out["ti"] = g.download(st, F.LH_VAR_THETA_I)
+    if m != O.MODEL_RICHARDS:
+        out["rhoe"] = g.download(st, F.LH_VAR_RHOE_INT)
+    return out
+
+
+def _run(case, tune, nsteps, dt):
+    with pc.GpuModel(case) as g:
+        F, L = g.F, g.L
+        F.check(L.lh_set_tuning(g.ctx, tune), g.ctx)
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        g.rhs(Y, Ya, dY)
+        res = {"rhs": _fields(g, dY, case)}
+        import torch
+        dev = torch.zeros(1, device="cuda", dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
+        if case.om.model != O.MODEL_HEAT or True:
+            F.check(L.lh_rhs_stable_dt(g.ctx, 0.0, Y, Ya, dY, 0.4, C.c_void_p(dev.data_ptr())), g.ctx)
+            F.check(L.lh_synchronize(g.ctx), g.ctx)
+            res["rhs4"] = _fields(g, dY, case)
+            res["dt"] = {"dt": dev.cpu().numpy().copy()}
+        g.status()
+        F.check(L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, dt, nsteps, None), g.ctx)
+        res["step"] = _fields(g, Y, case)
+        return res
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_segmented_launch_is_bitwise_the_unsegmented_one(name):
+    case = pc.make_case(name)
+    dt = 1e-3 if "mixed_factors" in name else 0.5
+    ref = _run(case, b"seg=-1", 3, dt)
+    for tune in SEGS:
+        got = _run(case, tune, 3, dt)
+        for part in ref:
+            for k in ref[part]:
+                np.testing.assert_array_equal(got[part][k], ref[part][k],
+                                              err_msg=f"{name} {tune.decode()} {part}.{k}")
+
+
+def test_single_column_uses_segments_and_matches_oracle():
+    """The reference's own shape: ONE column.  The library cuts it into segments by
+    itself; the result is the oracle's (and the unsegmented launch's)."""
+    case = pc.make_case("c1_dirichlet_f64")
+    assert case.ncols == 1
+    got = pc.run_gpu_rhs(case)
+    want = pc.run_oracle_rhs(case)
+    pc.assert_tendencies_close(case, got, want, 4.0)
