@@ -737,24 +737,44 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
 #undef LH_GO
 }
 
+// All rhs_kernel variants of one model.  Each (FT, MODEL) pair is instantiated in its own
+// translation unit (lh_kernels_<ft>_<model>.hip) so the build runs eight compilers side by side.
+template <typename FT, int MODEL>
+void launch_rhs_for_model(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
+                          const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
+                          int mode, bool factors, bool percol, int math, const Tune& tune,
+                          hipStream_t s) {
+    // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
+    // the fused SSPRK33 stages and mode 4 always run the production math.
+    if (math == MATH_LIBM && mode == 0)
+        launch_rhs_model<FT, MODEL, MathLibm<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s);
+    else
+        launch_rhs_model<FT, MODEL, MathFast<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s);
+}
+
+#define LH_RHS_MODEL_ARGS(FT)                                                                        \
+    const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, \
+        FT, const FT*, int, bool, bool, int, const Tune&, hipStream_t
+#ifndef LH_TU_MODEL // the common translation unit only dispatches
+extern template void launch_rhs_for_model<double, MODEL_RICHARDS>(LH_RHS_MODEL_ARGS(double));
+extern template void launch_rhs_for_model<double, MODEL_HEAT>(LH_RHS_MODEL_ARGS(double));
+extern template void launch_rhs_for_model<double, MODEL_COUPLED>(LH_RHS_MODEL_ARGS(double));
+extern template void launch_rhs_for_model<float, MODEL_RICHARDS>(LH_RHS_MODEL_ARGS(float));
+extern template void launch_rhs_for_model<float, MODEL_HEAT>(LH_RHS_MODEL_ARGS(float));
+extern template void launch_rhs_for_model<float, MODEL_COUPLED>(LH_RHS_MODEL_ARGS(float));
+#endif
+#define LH_INSTANTIATE_MODEL(FT, MODEL) \
+    template void launch_rhs_for_model<FT, MODEL>(LH_RHS_MODEL_ARGS(FT));
+
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
                 bool factors, bool percol, int math, const Tune& tune, hipStream_t s) {
-#define LH_DISPATCH_MODEL(MATH)                                                                 \
-    switch (P.model) {                                                                          \
-        case MODEL_RICHARDS: launch_rhs_model<FT, MODEL_RICHARDS, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break; \
-        case MODEL_HEAT: launch_rhs_model<FT, MODEL_HEAT, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break;         \
-        default: launch_rhs_model<FT, MODEL_COUPLED, MATH>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s); break;              \
+    switch (P.model) {
+        case MODEL_RICHARDS: launch_rhs_for_model<FT, MODEL_RICHARDS>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
+        case MODEL_HEAT: launch_rhs_for_model<FT, MODEL_HEAT>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
+        default: launch_rhs_for_model<FT, MODEL_COUPLED>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
     }
-    // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
-    // the fused SSPRK33 stages always run the production math.
-    if (math == MATH_LIBM && mode == 0) { // (mode 4 always runs the production math)
-        LH_DISPATCH_MODEL(MathLibm<FT>)
-    } else {
-        LH_DISPATCH_MODEL(MathFast<FT>)
-    }
-#undef LH_DISPATCH_MODEL
 }
 
 template <typename FT>

@@ -10,8 +10,8 @@ out=$root/landhydrology.jl_amd/lib/variants
 tmp=$(mktemp -d /tmp/lh_variant.XXXXXX)
 mkdir -p "$out"
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function"
-for f in lh_api lh_kernels_f64 lh_kernels_f32; do
-    /opt/rocm/bin/hipcc $flags "$@" -c "$src/$f.hip" -o "$tmp/$f.o" &
+for f in "$src"/*.hip; do
+    /opt/rocm/bin/hipcc $flags "$@" -c "$f" -o "$tmp/$(basename "$f" .hip).o" &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$out/liblandhydro_hip_$name.so" "$tmp"/*.o
