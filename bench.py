@@ -127,9 +127,18 @@ def cpu_baseline(case, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 2000:
             break
+    # the same restatement on ONE thread (the reference has no threading): ~2 s of it
+    r1, t1 = 0, time.perf_counter()
+    while True:
+        pc.run_oracle_rhs(sub, nthreads=1)
+        r1 += 1
+        el1 = time.perf_counter() - t1
+        if el1 >= min(2.0, seconds) or r1 >= 50:
+            break
     import shutil
     julia = shutil.which("julia")
     return {"value": sample * n * reps / el, "unit": "cell-updates/s", "cores": threads,
+            "single_thread_value": sample * n * r1 / el1,
             "kind": "port",
             "reference_julia": ("julia found at %s but LandHydrology.jl's un-vendored dependencies "
                                 "(ClimaCore, CLIMAParameters, OrdinaryDiffEq) are not shipped with this "
