@@ -241,6 +241,7 @@ void parse_tune(Tune& tu, const char* t) {
     tu = Tune();
     int v;
     const char* q;
+    if ((q = strstr(t, "graph=")) && sscanf(q + 6, "%d", &v) == 1 && (v == 0 || v == 1)) tu.graph = v;
     if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
@@ -983,18 +984,55 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     lh_state* U1 = c->scratch_u1;
     lh_state* U2 = U1;
     if ((rc = second_stage_state(c, &U2))) return rc;
-    for (int64_t s = 0; s < nsteps; ++s) {
+    auto one_step = [&](const double* bc3) -> int {
         for (int stage = 0; stage < 3; ++stage) {
-            const double* ov = bcv ? bcv + (s * 3 + stage) * 4 : nullptr;
+            const double* ov = bc3 ? bc3 + stage * 4 : nullptr;
             // stage 1: U1 = Y + dt f(Y); 2: U2 = (3Y + U1 + dt f(U1))/4; 3: Y = (Y + 2U2 + 2dt f(U2))/3
             // (U2 is U1 itself unless the launch is level-segmented)
             const lh_state* in = stage == 0 ? Y : (stage == 1 ? U1 : U2);
             lh_state* out = stage == 2 ? Y : (stage == 1 ? U2 : U1);
-            rc = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, dt, stage + 1, ov)
-                                        : do_rhs<float>(c, in, Ya, Y, out, dt, stage + 1, ov);
-            if (rc) return rc;
+            int r = c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, dt, stage + 1, ov)
+                                           : do_rhs<float>(c, in, Ya, Y, out, dt, stage + 1, ov);
+            if (r) return r;
+        }
+        return LH_OK;
+    };
+    int64_t done = 0;
+    // Small ensembles with constant boundary values: the launches themselves are the cost of a
+    // step (a few microseconds of device work each), so a block of steps is captured once into
+    // a hipGraph and replayed.  Anything that goes wrong with the capture falls back to plain
+    // launches of whatever is left.
+    constexpr int GRAPH_STEPS = 16;
+    if (!bcv && c->tune.graph != 0 && segment_length(c) > 0 && nsteps >= 4 * GRAPH_STEPS) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int k = 0; k < GRAPH_STEPS && !rc; ++k) rc = one_step(nullptr);
+            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph && !rc;
+            if (rc) { // a launch was refused while capturing: nothing has run yet
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                return rc;
+            }
+        }
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (ok)
+            for (; done + GRAPH_STEPS <= nsteps; done += GRAPH_STEPS)
+                if (hipGraphLaunch(exec, c->stream) != hipSuccess) {
+                    ok = false;
+                    break;
+                }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {
+            const hipError_t e = hipGetLastError();
+            if (done > 0 && done < nsteps && e != hipSuccess)
+                return fail(c, LH_ENODEVICE, "hipGraphLaunch failed after %lld steps: %s", (long long)done, hipGetErrorString(e));
         }
     }
+    for (int64_t s = done; s < nsteps; ++s)
+        if ((rc = one_step(bcv ? bcv + s * 12 : nullptr))) return rc;
     return LH_OK;
 }
 

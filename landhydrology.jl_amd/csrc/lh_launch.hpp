@@ -20,6 +20,7 @@ struct Tune {
     int arena = 0; // plane slots per device allocation (0 = default)
     int rowpad = -1; // extra elements per plane row (-1 = library default)
     int seg = 0;     // levels per segment of the level-segmented launch (0 = automatic, -1 = never)
+    int graph = 1;   // replay blocks of fused SSPRK33 steps of small ensembles as a hipGraph (0: plain launches)
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
 };
 

@@ -21,7 +21,8 @@ for wl, ncols in (("c2", 1), ("c2", 1024), ("c3", 1), ("c3", 16384), ("c2", 6553
     F.check(g.L.lh_synchronize(g.ctx), g.ctx)
     t0 = time.perf_counter()
     F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, 1e-6, nsteps, None), g.ctx)
+    enq = time.perf_counter() - t0
     F.check(g.L.lh_synchronize(g.ctx), g.ctx)
     el = time.perf_counter() - t0
-    print(f"{wl} ncols={ncols:6d}: {el / nsteps * 1e6:8.2f} us per step ({el / nsteps / 3 * 1e6:.2f} us per stage launch)", flush=True)
+    print(f"{wl} ncols={ncols:6d}: {el / nsteps * 1e6:8.2f} us per step ({el / nsteps / 3 * 1e6:.2f} us per stage launch; host enqueue {enq / nsteps * 1e6:.2f} us per step)", flush=True)
     g.close()
