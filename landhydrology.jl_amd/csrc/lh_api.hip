@@ -233,6 +233,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.dt_out = nullptr;
     P.xcd_remap = 0;
     P.seg_len = segment_length(c);
+    P.cs_cpb = c->tune.cpb;
     return P;
 }
 
@@ -241,6 +242,8 @@ void parse_tune(Tune& tu, const char* t) {
     tu = Tune();
     int v;
     const char* q;
+    if ((q = strstr(t, "cpb=")) && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v <= 16) tu.cpb = v;
+    if ((q = strstr(t, "persist=")) && sscanf(q + 8, "%d", &v) == 1 && v >= 0 && v <= 2) tu.persist = v;
     if ((q = strstr(t, "graph=")) && sscanf(q + 6, "%d", &v) == 1 && (v == 0 || v == 1)) tu.graph = v;
     if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
@@ -426,6 +429,69 @@ void state_free(lh_ctx* c, lh_state* s) {
             break;
         }
     delete s;
+}
+
+// The persistent column stepper (workgroup = columns, thread = cell) keeps the state in
+// registers over all steps of a call: 0.71 ms per step on 1e6 x 64 Float64 columns against
+// 1.06 ms for three fused-stage launches, and 2-3 us per step for a single column.  Getting
+// the level-fastest registers from and to the column-fastest planes costs ~0.7 ms per call at
+// that size, so large ensembles take it from 3 steps per call on (and only without Dirichlet
+// faces, see below); small ones (<= 2^20 threads) always.  Not for columns with more levels than a workgroup has threads.
+// LH_TUNE=persist=0: never (fused-stage launches), persist=2: always.
+bool use_column_stepper(const lh_ctx* c, int64_t nsteps) {
+    if (c->tune.persist == 0 || c->cfg.nlev > 1024) return false;
+    if (c->tune.persist == 2) return true;
+    const int64_t threads = c->cfg.ncols * int64_t((c->cfg.nlev + 63) / 64 * 64);
+    if (threads <= (int64_t(1) << 20)) return true;
+    // A Dirichlet face needs the closures of the face state.  rhs_kernel evaluates them for 64
+    // columns at once; here the one thread next to the face does, with its whole wave waiting:
+    // a second closure pass per stage (3.6 vs 2.1 ms per step on the f3c64 workload).  Large
+    // ensembles with a Dirichlet face stay with the fused-stage launches.
+    for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < 2; ++k)
+            if (c->hp.bc_kind[f][k] == LH_BC_DIRICHLET) return false;
+    return nsteps >= 3;
+}
+
+int run_column_stepper(lh_ctx* c, lh_state* Y, const lh_state* Ya, double dt, const void* dt_device,
+                       int64_t nsteps, const double* bcv) {
+    if (nsteps <= 0) return LH_OK;
+    void* d_bcv = nullptr;
+    if (bcv) { // [nsteps][3][2][2] doubles -> FT on the device
+        const size_t nv = size_t(nsteps) * 12;
+        std::vector<char> tmp(nv * c->esize);
+        for (size_t k = 0; k < nv; ++k) {
+            if (c->cfg.dtype == LH_F64) reinterpret_cast<double*>(tmp.data())[k] = bcv[k];
+            else reinterpret_cast<float*>(tmp.data())[k] = float(bcv[k]);
+        }
+        LH_HIP(c, hipMalloc(&d_bcv, nv * c->esize));
+        hipError_t e = hipMemcpyAsync(d_bcv, tmp.data(), nv * c->esize, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // tmp is pageable host memory
+        if (e != hipSuccess) {
+            (void)hipFree(d_bcv);
+            return fail(c, LH_ENODEVICE, "boundary-value upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    if (c->cfg.dtype == LH_F64) {
+        DevParams<double> P = make_params<double>(c);
+        launch_column_stepper<double>(P, planes_of<double>(Y), planes_of<double>(Ya), dt,
+                                      static_cast<const double*>(dt_device), nsteps,
+                                      static_cast<const double*>(d_bcv), factors, any_percol(c), c->stream);
+    } else {
+        DevParams<float> P = make_params<float>(c);
+        launch_column_stepper<float>(P, planes_of<float>(Y), planes_of<float>(Ya), float(dt),
+                                     static_cast<const float*>(dt_device), nsteps,
+                                     static_cast<const float*>(d_bcv), factors, any_percol(c), c->stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (d_bcv) { // the launch reads it: wait before releasing
+        const hipError_t e2 = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_bcv);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e != hipSuccess) return fail(c, LH_ENODEVICE, "column stepper launch failed: %s", hipGetErrorString(e));
+    return LH_OK;
 }
 
 // A level-segmented stage reads cells its neighbour segments write: it needs a target
@@ -979,6 +1045,9 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     if ((rc = check_state(c, Y, pm, "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
+    // Default: all nsteps in ONE launch of the persistent column stepper (state in registers,
+    // no plane traffic between stages or steps; column_stepper_kernel)
+    if (use_column_stepper(c, nsteps)) return run_column_stepper(c, Y, Ya, dt, nullptr, nsteps, bcv);
     // the stage state carries no theta_i plane: the fused stages read theta_i from Y
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
@@ -1046,6 +1115,7 @@ int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double
     if ((rc = check_state(c, Y, pm, "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
+    if (use_column_stepper(c, 1)) return run_column_stepper(c, Y, Ya, 0.0, dt_device_ft, 1, bcv);
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
     lh_state* U2 = U1;
@@ -1128,7 +1198,7 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
     (void)hipSetDevice(c->device);
     const bool f64 = c->cfg.dtype == LH_F64;
     lh_state* written = dY;
-    if (!dY && segment_length(c) > 0) { // small ensemble (cache-resident, two stage states): nothing to place
+    if (!dY && (use_column_stepper(c, 1) || segment_length(c) > 0)) { // no stage state in HBM, or a cache-resident one
         if (ms_before) *ms_before = 0;
         if (ms_after) *ms_after = 0;
         return LH_OK;

@@ -71,6 +71,7 @@ struct DevParams {
     uint32_t* status; // device word; bit 0 = non-finite tendency seen
     const double* math_tab; // device copy of the log2/exp2 tables (lh_fastmath.hpp)
     void* dt_out;           // MODE 4: FT-sized device word receiving the stable-step minimum
+    int32_t cs_cpb;         // persistent column stepper: columns per workgroup (0 = launcher's choice)
     int32_t seg_len;        // > 0: level-segmented launch, levels per segment (small ensembles)
     int32_t xcd_remap;      // workgroup -> column-block map that gives each XCD one contiguous column range
 };

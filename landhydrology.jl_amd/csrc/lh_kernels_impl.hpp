@@ -469,6 +469,177 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     }
 }
 
+// --------------------------------------------- persistent column stepper
+//
+// Ensembles of a few columns (the reference's own shape is ONE column): even
+// level-segmented, a fused SSPRK33 step is three dependent launches of ~6 us each.
+// Here one workgroup owns one column and one thread one CELL, the state lives in
+// registers, and the whole loop over steps and stages runs inside one launch: per
+// stage every thread evaluates the closures of its cell, publishes K, h (T, kappa,
+// rho_e_l K) in LDS, and forms the flux of the face below and the face above it from
+// its neighbours' values -- each interior face is evaluated by both adjacent threads
+// with the expression of rhs_kernel (lower cell first), so the step is bitwise the
+// fused-stage one and conservation is untouched.  Two barriers per stage.
+// bcv: NULL or [nsteps][3][2][2] FT boundary values (step, stage, face, component).
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
+__global__ void __launch_bounds__(1024)
+column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
+                      const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const int n = P0.nlev;
+    // a workgroup holds blockDim.x / tpc columns of tpc = roundup(n, 64) threads each (they
+    // share the staged math tables; the barriers couple them, which costs nothing)
+    const int tpc = (n + 63) & ~63;
+    const int slot = int(threadIdx.x) / tpc;
+    const int cpb = int(blockDim.x) / tpc;
+    const FT dt = dt_device ? *dt_device : dt_value;
+    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * 5 * n;
+    FT* sh = sK + n;
+    FT* sT = sh + n;
+    FT* sKap = sT + n;
+    FT* sE = sKap + n;
+    const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
+    if (!M::uses_tables) __syncthreads();
+    DevParams<FT> P = P0; // boundary values change per stage
+    const int i = int(threadIdx.x) - slot * tpc;
+    // XCD-contiguous workgroup map (as rhs_kernel): neighbouring workgroups share the 128-byte
+    // lines their 16..64-byte pieces of a plane row lie in, so they must share an L2
+    unsigned blk = blockIdx.x;
+    if (P.xcd_remap) {
+        const unsigned per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const int64_t col_raw = int64_t(blk) * cpb + slot;
+    const bool cell = i < n && col_raw < P.ncols;
+    const int ic = i < n ? i : n - 1;
+    const int64_t col = col_raw < P.ncols ? col_raw : P.ncols - 1; // spare slots shadow the last column
+    const ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
+    // Planes are column-fastest, threads here are level-fastest: go through LDS tiles so that
+    // global memory sees the cpb adjacent columns of a level as one contiguous piece.  All
+    // planes are requested before the one barrier (a block is short-lived when nsteps is
+    // small: serialised round trips to HBM would dominate it).
+    FT* tiles = reinterpret_cast<FT*>(s_dyn); // up to 5 tiles [cpb][n], the exchange arrays' space
+    const int64_t col_first = int64_t(blk) * cpb;
+    const int tile_n = n * cpb;
+    auto request = [&](const FT* plane, int k) {
+        for (int e = threadIdx.x; e < tile_n; e += blockDim.x) {
+            const int lev = e / cpb, cs = e - lev * cpb;
+            if (col_first + cs < P.ncols) tiles[k * tile_n + cs * n + lev] = plane[int64_t(lev) * P.stride + col_first + cs];
+        }
+    };
+    auto fetched = [&](int k) -> FT { return (col_raw < P.ncols) ? tiles[k * tile_n + slot * n + ic] : FT(0); };
+    // HEAT reads the prescribed water fields from Ya (right_hand_side.jl:200-201)
+    request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
+    request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
+    if (HEAT) request(Y.v[2], 2);
+    if (need_Taux) request(AUX.v[3], 3);
+    __syncthreads();
+    FT y_vl = fetched(0);
+    const FT ti = fetched(1);
+    FT y_re = HEAT ? fetched(2) : FT(0);
+    const FT Ta = need_Taux ? fetched(3) : FT(288);
+    __syncthreads();
+    const FT z = P.zc[ic];
+    FT nf_acc = FT(0);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        FT u_vl = y_vl, u_re = y_re; // the stage state
+#pragma unroll 1
+        for (int stage = 0; stage < 3; ++stage) {
+            if (bcv) {
+                const FT* b = bcv + (s * 3 + stage) * 4;
+                P.bc_value[0][0] = b[0];
+                P.bc_value[0][1] = b[1];
+                P.bc_value[1][0] = b[2];
+                P.bc_value[1][1] = b[3];
+            }
+            FT T = Ta, kap = FT(0), K = FT(0), psi = FT(0), h = FT(0), E = FT(0), rcs = FT(1);
+            if (HEAT) {
+                T = temperature_closure<FT, M>(mm, P, c, u_vl, ti, u_re, rcs);
+                kap = kappa_closure<FT, M>(mm, P, c, u_vl, ti);
+            }
+            if (WATER) {
+                water_closures<FT, M, FACTORS, true, false>(mm, P, c, u_vl, ti, T, K, psi);
+                h = psi + z;
+                if (HEAT) E = (P.rhocp_l * (T - P.T_ref)) * K; // rho_e_int_l * K (:364)
+            }
+            if (i < n) {
+                if (WATER) { sK[i] = K; sh[i] = h; }
+                if (HEAT) { sT[i] = T; sKap[i] = kap; }
+                if (HEAT && WATER) sE[i] = E;
+            }
+            __syncthreads();
+            FT Fw_lo = FT(0), Fe_lo = FT(0), Fw_hi = FT(0), Fe_hi = FT(0);
+            if (i < n) {
+                if (i == 0) {
+                    boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_BOTTOM, col, u_vl, ti, T, K, psi, Fe_lo, Fw_lo);
+                } else {
+                    FT gh = FT(0);
+                    if (WATER) {
+                        gh = (h - sh[i - 1]) * P.inv_dz;
+                        Fw_lo = -((sK[i - 1] + K) * FT(0.5)) * gh;
+                    }
+                    if (HEAT) {
+                        const FT gT = (T - sT[i - 1]) * P.inv_dz;
+                        Fe_lo = -((sKap[i - 1] + kap) * FT(0.5)) * gT;
+                        if (WATER) Fe_lo = Fe_lo - ((sE[i - 1] + E) * FT(0.5)) * gh;
+                    }
+                }
+                if (i == n - 1) {
+                    boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
+                } else {
+                    FT gh = FT(0);
+                    if (WATER) {
+                        gh = (sh[i + 1] - h) * P.inv_dz;
+                        Fw_hi = -((K + sK[i + 1]) * FT(0.5)) * gh;
+                    }
+                    if (HEAT) {
+                        const FT gT = (sT[i + 1] - T) * P.inv_dz;
+                        Fe_hi = -((kap + sKap[i + 1]) * FT(0.5)) * gT;
+                        if (WATER) Fe_hi = Fe_hi - ((E + sE[i + 1]) * FT(0.5)) * gh;
+                    }
+                }
+            }
+            const FT dvl = WATER ? -((Fw_hi - Fw_lo) * P.inv_dz) : FT(0);
+            const FT dre = HEAT ? -((Fe_hi - Fe_lo) * P.inv_dz) : FT(0);
+            if (cell) {
+                if (WATER) nf_acc = fma_ft(dvl, FT(0), nf_acc);
+                if (HEAT) nf_acc = fma_ft(dre, FT(0), nf_acc);
+            }
+            // the stage updates of rhs_kernel MODE 1..3 (b = Y, u = stage state)
+            auto upd = [&](FT b, FT u, FT k) -> FT {
+                if (stage == 0) return u + dt * k;
+                if (stage == 1) return (FT(3) * b + u + dt * k) * FT(0.25);
+                const FT sum = b + FT(2) * u + FT(2) * dt * k;
+                const FT q = sum * FT(1.0 / 3.0);
+                return fma_ft(fma_ft(FT(-3), q, sum), FT(1.0 / 3.0), q);
+            };
+            if (WATER) u_vl = upd(y_vl, u_vl, dvl);
+            if (HEAT) u_re = upd(y_re, u_re, dre);
+            __syncthreads(); // neighbours have read this stage's LDS values
+        }
+        y_vl = u_vl;
+        y_re = u_re;
+    }
+    if (i < n) {
+        if (WATER) tiles[slot * n + i] = y_vl;
+        if (HEAT) tiles[tile_n + slot * n + i] = y_re;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tile_n; e += blockDim.x) {
+        const int lev = e / cpb, cs = e - lev * cpb;
+        if (col_first + cs < P.ncols) {
+            const int64_t g = int64_t(lev) * P.stride + col_first + cs;
+            if (WATER) Y.v[0][g] = tiles[cs * n + lev];
+            if (HEAT) Y.v[2][g] = tiles[tile_n + cs * n + lev];
+        }
+    }
+    if (cell && nf_acc != nf_acc) atomicOr(P.status, 1u);
+}
+
 // --------------------------------------------------------- diagnostics
 // K, psi, kappa, T of every cell (the pointwise stage only).
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
@@ -752,6 +923,30 @@ void launch_rhs_for_model(const DevParams<FT>& P, const Planes<FT>& in, const Pl
         launch_rhs_model<FT, MODEL, MathFast<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s);
 }
 
+template <typename FT, int MODEL>
+void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux,
+                                     FT dt, const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors,
+                                     bool percol, hipStream_t s) {
+    const unsigned tpc = (unsigned)((P.nlev + 63) / 64 * 64);
+    // columns per workgroup
+    unsigned cpb = 256u / tpc ? 256u / tpc : 1u; // 256-thread workgroups measured best (1e6 columns)
+    if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;
+    dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
+    const unsigned dyn = (unsigned)(cpb * 5 * (size_t)P.nlev * sizeof(FT));
+    using M = MathFast<FT>;
+#define LH_CS(F, PC) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv)
+    if (factors) {
+        if (percol) LH_CS(true, true);
+        else LH_CS(true, false);
+    } else {
+        if (percol) LH_CS(false, true);
+        else LH_CS(false, false);
+    }
+#undef LH_CS
+}
+
+#define LH_CS_MODEL_ARGS(FT) \
+    const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, FT, const FT*, int64_t, const FT*, bool, bool, hipStream_t
 #define LH_RHS_MODEL_ARGS(FT)                                                                        \
     const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, \
         FT, const FT*, int, bool, bool, int, const Tune&, hipStream_t
@@ -762,9 +957,16 @@ extern template void launch_rhs_for_model<double, MODEL_COUPLED>(LH_RHS_MODEL_AR
 extern template void launch_rhs_for_model<float, MODEL_RICHARDS>(LH_RHS_MODEL_ARGS(float));
 extern template void launch_rhs_for_model<float, MODEL_HEAT>(LH_RHS_MODEL_ARGS(float));
 extern template void launch_rhs_for_model<float, MODEL_COUPLED>(LH_RHS_MODEL_ARGS(float));
+extern template void launch_column_stepper_for_model<double, MODEL_RICHARDS>(LH_CS_MODEL_ARGS(double));
+extern template void launch_column_stepper_for_model<double, MODEL_HEAT>(LH_CS_MODEL_ARGS(double));
+extern template void launch_column_stepper_for_model<double, MODEL_COUPLED>(LH_CS_MODEL_ARGS(double));
+extern template void launch_column_stepper_for_model<float, MODEL_RICHARDS>(LH_CS_MODEL_ARGS(float));
+extern template void launch_column_stepper_for_model<float, MODEL_HEAT>(LH_CS_MODEL_ARGS(float));
+extern template void launch_column_stepper_for_model<float, MODEL_COUPLED>(LH_CS_MODEL_ARGS(float));
 #endif
-#define LH_INSTANTIATE_MODEL(FT, MODEL) \
-    template void launch_rhs_for_model<FT, MODEL>(LH_RHS_MODEL_ARGS(FT));
+#define LH_INSTANTIATE_MODEL(FT, MODEL)                                    \
+    template void launch_rhs_for_model<FT, MODEL>(LH_RHS_MODEL_ARGS(FT)); \
+    template void launch_column_stepper_for_model<FT, MODEL>(LH_CS_MODEL_ARGS(FT));
 
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
@@ -774,6 +976,17 @@ void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& 
         case MODEL_RICHARDS: launch_rhs_for_model<FT, MODEL_RICHARDS>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
         case MODEL_HEAT: launch_rhs_for_model<FT, MODEL_HEAT>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
         default: launch_rhs_for_model<FT, MODEL_COUPLED>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
+    }
+}
+
+template <typename FT>
+void launch_column_stepper(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux, FT dt,
+                           const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors, bool percol,
+                           hipStream_t s) {
+    switch (P.model) {
+        case MODEL_RICHARDS: launch_column_stepper_for_model<FT, MODEL_RICHARDS>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
+        case MODEL_HEAT: launch_column_stepper_for_model<FT, MODEL_HEAT>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
+        default: launch_column_stepper_for_model<FT, MODEL_COUPLED>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
     }
 }
 
@@ -849,6 +1062,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
     template void launch_rhs<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,          \
                                  const Planes<FT>&, const Planes<FT>&, FT, const FT*, int, bool, bool, \
                                  int, const Tune&, hipStream_t);                                                      \
+    template void launch_column_stepper<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, \
+                                            FT, const FT*, int64_t, const FT*, bool, bool, hipStream_t); \
     template void launch_diag<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,         \
                                   const Planes<FT>&, bool, int, hipStream_t);                         \
     template void launch_stable_dt<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,    \

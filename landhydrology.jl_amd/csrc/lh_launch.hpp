@@ -20,6 +20,8 @@ struct Tune {
     int arena = 0; // plane slots per device allocation (0 = default)
     int rowpad = -1; // extra elements per plane row (-1 = library default)
     int seg = 0;     // levels per segment of the level-segmented launch (0 = automatic, -1 = never)
+    int cpb = 0;     // persistent column stepper: columns per workgroup (0 = default)
+    int persist = 1; // persistent column stepper (0: fused-stage launches instead)
     int graph = 1;   // replay blocks of fused SSPRK33 steps of small ensembles as a hipGraph (0: plain launches)
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
 };
@@ -29,6 +31,11 @@ template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
                 bool factors, bool percol, int math, const Tune& tune, hipStream_t s);
+// nsteps fused SSPRK33 steps of a small ensemble in ONE launch (workgroup = column, thread = cell)
+template <typename FT>
+void launch_column_stepper(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux, FT dt,
+                           const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors, bool percol,
+                           hipStream_t s);
 template <typename FT>
 void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                  const Planes<FT>& out, bool percol, int math, hipStream_t s);

@@ -72,6 +72,7 @@ def test_stepper_stage_state_tuning(name, ncols, dt, flags):
     for tune in (False, True):
         with pc.GpuModel(case) as g:
             F, L = g.F, g.L
+            F.check(L.lh_set_tuning(g.ctx, b"persist=0"), g.ctx)   # the fused-stage stepper owns a stage state
             Y, Ya = g.prognostic_and_aux()
             y0 = _fields(g, Y, case)
             if tune:

@@ -20,7 +20,8 @@ O = pc.O
 CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c3_coupled_f32", "c3_coupled_f64",
          "c5_percol_f64", "heat_dirichlet_f64", "heat_dirichlet_f32", "mixed_factors_f64",
          "mixed_smooth_f32", "richards_viscosity_f64"]
-SEGS = [b"seg=8", b"seg=5", b"seg=1", b"seg=0"]          # seg=0: the library's own choice
+SEGS = [b"seg=8,persist=0", b"seg=5,persist=0", b"seg=1,persist=0", b"seg=0,persist=0"]   # seg=0: the library's own choice
+# (persist=0: the fused-stage launches, not the persistent column stepper, do the stepping)
 
 
 def _fields(g, st, case):
@@ -59,7 +60,7 @@ def _run(case, tune, nsteps, dt):
 def test_segmented_launch_is_bitwise_the_unsegmented_one(name):
     case = pc.make_case(name)
     dt = 1e-3 if "mixed_factors" in name else 0.5
-    ref = _run(case, b"seg=-1", 3, dt)
+    ref = _run(case, b"seg=-1,persist=0", 3, dt)
     for tune in SEGS:
         got = _run(case, tune, 3, dt)
         for part in ref:
@@ -85,7 +86,7 @@ def test_graph_replayed_steps_equal_plain_launches(name):
     across a step count that is not a multiple of the block."""
     case = pc.make_case(name)
     res = []
-    for tune in (b"graph=0", b"graph=1"):
+    for tune in (b"graph=0,persist=0", b"graph=1,persist=0"):
         with pc.GpuModel(case) as g:
             g.F.check(g.L.lh_set_tuning(g.ctx, tune), g.ctx)
             Y, Ya = g.prognostic_and_aux()
@@ -94,3 +95,32 @@ def test_graph_replayed_steps_equal_plain_launches(name):
             assert g.status() == 0
     for k in res[0]:
         np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", CASES + ["single_cell_f64"])
+def test_persistent_column_stepper_is_bitwise_the_fused_stages(name):
+    """Ensembles of few columns step inside ONE launch (workgroup = column, thread = cell,
+    column_stepper_kernel).  Same closures, same face expressions, same stage updates as
+    the fused-stage launches: the stepped state must be bitwise equal -- with constant and
+    with per-stage boundary values."""
+    case = pc.make_case(name)
+    dt = 1e-3 if "mixed_factors" in name else 0.5
+    nsteps = 7
+    rng = np.random.default_rng(5)
+    base = np.zeros((2, 2))
+    for (f, comp), (kind, v) in case.om.bc.items():
+        base[f, comp] = v
+    bcv = np.broadcast_to(base, (nsteps, 3, 2, 2)) * (1.0 + 1e-3 * rng.standard_normal((nsteps, 3, 1, 1)))
+    bcv = np.ascontiguousarray(bcv, dtype=np.float64)
+    for use_bcv in (False, True):
+        res = []
+        for tune in (b"persist=0,seg=-1", b"persist=1"):
+            with pc.GpuModel(case) as g:
+                g.F.check(g.L.lh_set_tuning(g.ctx, tune), g.ctx)
+                Y, Ya = g.prognostic_and_aux()
+                p = bcv.ctypes.data_as(C.POINTER(C.c_double)) if use_bcv else None
+                g.F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, dt, nsteps, p), g.ctx)
+                res.append((_fields(g, Y, case), g.status()))
+        assert res[0][1] == res[1][1]
+        for k in res[0][0]:
+            np.testing.assert_array_equal(res[0][0][k], res[1][0][k], err_msg=f"{name} bcv={use_bcv} {k}")
