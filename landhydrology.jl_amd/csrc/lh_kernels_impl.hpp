@@ -573,9 +573,17 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             }
             __syncthreads();
             FT Fw_lo = FT(0), Fe_lo = FT(0), Fw_hi = FT(0), Fe_hi = FT(0);
+            // boundary faces: the bottom thread and the top thread go through boundary_fluxes
+            // TOGETHER (one divergent pass, not two, when both faces need closures)
+            FT Fw_b = FT(0), Fe_b = FT(0);
+            const bool at_bottom = (i == 0), at_top = (i == n - 1);
+            if (i < n && (at_bottom || at_top))
+                boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, u_vl, ti,
+                                                       T, K, psi, Fe_b, Fw_b);
             if (i < n) {
-                if (i == 0) {
-                    boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_BOTTOM, col, u_vl, ti, T, K, psi, Fe_lo, Fw_lo);
+                if (at_bottom) {
+                    Fw_lo = Fw_b;
+                    Fe_lo = Fe_b;
                 } else {
                     FT gh = FT(0);
                     if (WATER) {
@@ -588,8 +596,13 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                         if (WATER) Fe_lo = Fe_lo - ((sE[i - 1] + E) * FT(0.5)) * gh;
                     }
                 }
-                if (i == n - 1) {
-                    boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
+                if (at_top) {
+                    if (at_bottom) // a one-cell column: the same thread owns both faces
+                        boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
+                    else {
+                        Fw_hi = Fw_b;
+                        Fe_hi = Fe_b;
+                    }
                 } else {
                     FT gh = FT(0);
                     if (WATER) {
