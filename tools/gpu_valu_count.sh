@@ -10,7 +10,7 @@ for f in glob.glob("$OUT/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in acc.items():
-    if "rhs_kernel" in k:
+    if "rhs_kernel" in k or "column_stepper" in k:
         iv=sum(v["SQ_INSTS_VALU"])/len(v["SQ_INSTS_VALU"]); w=sum(v["SQ_WAVES"])/len(v["SQ_WAVES"])
         print(k, "VALU/launch=%.4g waves=%d VALU per wave=%.1f"%(iv,w,iv/w))
 PY
