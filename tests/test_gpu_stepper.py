@@ -301,6 +301,14 @@ def test_full_size_properties(workload):
         rel = np.abs(vl1.sum(axis=1) - m0) / m0
         assert np.max(rel) < (1e-13 if case.dtype == np.float64 else 2e-6)
         assert np.max(np.abs(vl1 - case.vl)) > 0          # it moved
+        # the same three steps by the other engine (three fused-stage launches per step instead
+        # of the persistent column stepper) from the same start: bitwise the same state
+        Y2, _ = g.prognostic_and_aux()
+        F.check(g.L.lh_set_tuning(g.ctx, b"persist=0"), g.ctx)
+        F.check(g.L.lh_step_ssprk33(g.ctx, Y2, Ya, 0.0, dt, 3, None), g.ctx)
+        np.testing.assert_array_equal(g.download(Y2, F.LH_VAR_VARTHETA_L).astype(np.float64), vl1)
+        if workload == "c3":
+            np.testing.assert_array_equal(g.download(Y2, F.LH_VAR_RHOE_INT), g.download(Y, F.LH_VAR_RHOE_INT))
 
 
 def test_stable_dt_matches_oracle_and_device_dt_stepping():
