@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-process path on a single GPU)")
-    ap.add_argument("--stepper", action="store_true",
-                    help="also time the fused device SSPRK33 stepper (extra JSON field)")
+    ap.add_argument("--stepper", action="store_true", default=True,
+                    help="also time the device SSPRK33 stepper, both engines (extra JSON fields; default)")
+    ap.add_argument("--no-stepper", dest="stepper", action="store_false")
     return ap.parse_args()
 
 
