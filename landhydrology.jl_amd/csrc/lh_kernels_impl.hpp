@@ -481,7 +481,10 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 // with the expression of rhs_kernel (lower cell first), so the step is bitwise the
 // fused-stage one and conservation is untouched.  Two barriers per stage.
 // bcv: NULL or [nsteps][3][2][2] FT boundary values (step, stage, face, component).
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
+// WAVE: a column is one wavefront (nlev <= 64).  The neighbour exchange then needs no
+// workgroup barrier -- LDS operations of one wave execute in order -- so a workgroup can hold
+// many columns (wide contiguous pieces for the plane tiles) without coupling their arithmetic.
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE>
 __global__ void __launch_bounds__(1024)
 column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
                       const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
@@ -571,7 +574,8 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 if (HEAT) { sT[i] = T; sKap[i] = kap; }
                 if (HEAT && WATER) sE[i] = E;
             }
-            __syncthreads();
+            if (WAVE) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();
             FT Fw_lo = FT(0), Fe_lo = FT(0), Fw_hi = FT(0), Fe_hi = FT(0);
             // boundary faces: the bottom thread and the top thread go through boundary_fluxes
             // TOGETHER (one divergent pass, not two, when both faces need closures)
@@ -632,11 +636,13 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             };
             if (WATER) u_vl = upd(y_vl, u_vl, dvl);
             if (HEAT) u_re = upd(y_re, u_re, dre);
-            __syncthreads(); // neighbours have read this stage's LDS values
+            if (WAVE) __builtin_amdgcn_wave_barrier(); // neighbours have read this stage's LDS values
+            else __syncthreads();
         }
         y_vl = u_vl;
         y_re = u_re;
     }
+    if (WAVE) __syncthreads(); // the tiles overlay other columns' exchange arrays
     if (i < n) {
         if (WATER) tiles[slot * n + i] = y_vl;
         if (HEAT) tiles[tile_n + slot * n + i] = y_re;
@@ -942,12 +948,20 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
                                      bool percol, hipStream_t s) {
     const unsigned tpc = (unsigned)((P.nlev + 63) / 64 * 64);
     // columns per workgroup
-    unsigned cpb = 256u / tpc ? 256u / tpc : 1u; // 256-thread workgroups measured best (1e6 columns)
+    // columns per workgroup: 256 threads when the stages need workgroup barriers; 8 one-wave
+    // columns otherwise (64-byte pieces of every plane row: tile I/O 0.43 instead of 0.79 ms
+    // on 1e6 x 64 Float64, tools/microbench/tile_io_probe.hip)
+    const bool wave = tpc == 64;
+    unsigned cpb = wave ? 8u : (256u / tpc ? 256u / tpc : 1u);
     if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;
     dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
     const unsigned dyn = (unsigned)(cpb * 5 * (size_t)P.nlev * sizeof(FT));
     using M = MathFast<FT>;
-#define LH_CS(F, PC) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv)
+#define LH_CS(F, PC)                                                                                              \
+    do {                                                                                                          \
+        if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);  \
+        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
+    } while (0)
     if (factors) {
         if (percol) LH_CS(true, true);
         else LH_CS(true, false);
