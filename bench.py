@@ -254,6 +254,25 @@ def main():
             traffic = tr["total_bytes"]
     except (OSError, ValueError, KeyError):
         pass
+    # the same bytes as one launch moved by a plain device-to-device copy (hipMemcpyAsync through
+    # torch): the "measured copy ceiling" SURVEY 8(d) asks to report beside the spec peak
+    copy_gbs = None
+    try:
+        nb = int(cells * bytes_per_cell / 2)
+        src = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * nb / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9
+        del src, dst
+    except RuntimeError:
+        pass
     value = world * cells * a.steps / wall
     achieved = cells * bytes_per_cell / (kern_ms * 1e-3) / 1e9
     out = {
@@ -280,7 +299,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "kernel_reps": kreps, "bytes_per_cell": bytes_per_cell,
-                     "algorithmic_bytes_per_launch": cells * bytes_per_cell},
+                     "algorithmic_bytes_per_launch": cells * bytes_per_cell,
+                     "measured_copy_gbs": copy_gbs,
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
         "placement_tuning": placement,
     }
     if a.stepper:
