@@ -25,10 +25,18 @@ namespace lh {
 // The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
 // per-column / conductivity-factor variants and the libm debug policy keep what
 // they need (a bound there only produces scratch spills).
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF>
+// the plain Float32 coupled tendency launches (MODE 0 and 4) keep their column constants in VGPRs
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int MODE>
+constexpr bool f32_coupled_vgpr_constants() {
+    return sizeof(FT) == 4 && MODEL == MODEL_COUPLED && !FACTORS && !PERCOL && M::is_production &&
+           (MODE == 0 || MODE == 4);
+}
+
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE>
 constexpr int rhs_waves_per_simd() {
     if (!M::is_production || FACTORS || PERCOL) return 1;
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
+    if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return 7;
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
 }
@@ -158,7 +166,7 @@ __device__ __forceinline__ bool finite(FT x) {
 // as a global load it would sit in the vector-memory queue behind the next
 // level's prefetch and force a full vmcnt(0) drain every level.
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE>
-__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF>()))
+__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
@@ -232,6 +240,17 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     for (int j = 0; j < CPL; ++j) {
         colj[j] = col0 + j < P.ncols ? col0 + j : P.ncols - 1;
         c[j] = make_colc<FT, M>(P, colj[j], PERCOL);
+    }
+    // Float32 coupled tendency: with every uniform constant in SGPRs the kernel spills 45 of them
+    // to VGPR lanes (28 v_readlane per two cells).  Thirteen column constants held in VGPRs
+    // instead (and 72 rather than 64 VGPRs: 7 waves/SIMD) remove every spill: +1..2.5 %.
+    if constexpr (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) {
+        auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
+        ColC<FT>& q = c[0];
+        vr(q.nu); vr(q.theta_lim); vr(q.theta_r); vr(q.inv_por); vr(q.e_inv_m); vr(q.e_m); vr(q.e_one);
+        vr(q.e_inv_n); vr(q.e_log2_alpha); vr(q.Ksat); vr(q.inv_S_s); vr(q.inv_nu); vr(q.k_dry);
+#pragma unroll
+        for (int j = 1; j < CPL; ++j) c[j] = c[0];
     }
 
     FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
