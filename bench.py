@@ -320,12 +320,15 @@ def main():
             torch.cuda.synchronize()
             ms = s0.elapsed_time(s1) / (ns * calls)
             return {"ms_per_step": ms, "steps_per_call": ns, "cell_updates_per_s": 3 * cells / (ms * 1e-3)}
-        out["ssprk33"] = time_steps(30, 2)            # the library's own choice of engine
-        F.check(L.lh_set_tuning(ctx, b"persist=0"), ctx)
-        if not a.no_placement_tune:
-            F.check(L.lh_tune_placement(ctx, Y, Ya, None, 0, F.LH_PLACE_MOVE_INPUT, None, None), ctx)
-        out["ssprk33_fused_stages"] = time_steps(10, 1)
-        F.check(L.lh_set_tuning(ctx, b""), ctx)
+        try:    # extra fields only: never at the price of the headline line
+            out["ssprk33"] = time_steps(30, 2)            # the library's own choice of engine
+            F.check(L.lh_set_tuning(ctx, b"persist=0"), ctx)
+            if not a.no_placement_tune:
+                F.check(L.lh_tune_placement(ctx, Y, Ya, None, 0, F.LH_PLACE_MOVE_INPUT, None, None), ctx)
+            out["ssprk33_fused_stages"] = time_steps(10, 1)
+            F.check(L.lh_set_tuning(ctx, b""), ctx)
+        except Exception as e:      # noqa: BLE001
+            out["ssprk33_error"] = repr(e)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(case, a.cpu_seconds)
     gm.close()
