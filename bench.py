@@ -14,6 +14,10 @@ min-all-reduced over RCCL inside the timed region.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see the driver contract).
+
+tests/parity_cases.py supplies the synthetic-input generator (pure numpy) and the C-ABI
+harness (GpuModel); the CPU oracle under oracle/ is loaded and executed in the
+cpu_baseline leg only (tests/test_abi_cpu.py checks that input generation does not).
 """
 import argparse
 import ctypes as C

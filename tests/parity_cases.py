@@ -60,17 +60,40 @@ class Case:
     col_offset: int = 0
 
 
+# k_solid(nu_om = 0, nu_q = 0.92, kappa_quartz = 7.7, kappa_minerals = 2.5, kappa_om = 0.25) and
+# ksat_unfrozen / ksat_frozen(k_solid, nu = 0.5, kappa_l = 0.57 / kappa_ice = 2.29) of
+# test/SoilModel/coupled.jl:16-22, as literals: input generation (also bench.py's) executes
+# nothing of the oracle.  tests/test_oracle_pins.py checks them against the oracle's functions.
+COUPLED_K_SOLID = 7.037309762302548
+COUPLED_KSAT_UNFROZEN = 2.0028146605496104
+COUPLED_KSAT_FROZEN = 4.014403985110721
+
+
 def coupled_soil():
     """test/SoilModel/coupled.jl:3-32."""
-    f = lambda name, *a: O.fn(name, np.float64)(*a)
     nu = 0.5
-    k_solid = f("lho_k_solid", 0.0, 0.92, 7.7, 2.5, 0.25)
     sp = O.default_soil(nu=nu, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.92,
-                        rho_c_ds=(1 - nu) * 1.926e06, kappa_solid=k_solid,
-                        kappa_sat_unfrozen=f("lho_ksat_unfrozen", k_solid, nu, 0.57),
-                        kappa_sat_frozen=f("lho_ksat_frozen", k_solid, nu, 2.29))
+                        rho_c_ds=(1 - nu) * 1.926e06, kappa_solid=COUPLED_K_SOLID,
+                        kappa_sat_unfrozen=COUPLED_KSAT_UNFROZEN,
+                        kappa_sat_frozen=COUPLED_KSAT_FROZEN)
     vg = O.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
     return sp, vg
+
+
+def grid_np(zmin, zmax, n, dtype=np.float64):
+    """The uniform mesh of domain.jl:58-69 in numpy, for input generation: faces = the
+    correctly rounded zmin + k L / n (extended precision, as the oracle's lho_grid), centres =
+    face midpoints in FT, bottom first.  Bitwise lho_grid (tests/test_oracle_pins.py)."""
+    ft = np.dtype(dtype).type
+    lo, hi = ft(zmin), ft(zmax)
+    k = np.arange(1, n + 1).astype(np.longdouble)
+    x = np.longdouble(lo) + (np.longdouble(hi) - np.longdouble(lo)) * k / np.longdouble(n)
+    zf = np.empty(n + 1, dtype=dtype)
+    zf[0] = lo
+    zf[1:] = x.astype(dtype)
+    zf[n] = hi
+    zc = ((zf[:-1] + zf[1:]) / ft(2)).astype(dtype)
+    return zc, zf
 
 
 def _flux_bcs(energy=None, hydrology=None):
@@ -90,7 +113,7 @@ def sigmoid(x):
 def wetting_front(ncols, n, zmin, zmax, nu, col_offset=0):
     """C2: vl(c,i) = nu (0.35 + 0.5 sigma((z_i - z_f(c))/0.1)),
     z_f(c) = zmin + (0.2 + 0.6 u(c,0)) L."""
-    zc, _ = O.grid(zmin, zmax, n)
+    zc, _ = grid_np(zmin, zmax, n)
     c = np.arange(col_offset, col_offset + ncols)
     L = zmax - zmin
     zf = zmin + (0.2 + 0.6 * uhash(c, 0, n)) * L
@@ -124,7 +147,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         om = O.OracleModel(O.MODEL_COUPLED, n, zmin, zmax, soil=sp, vg=vg,
                            bc=_flux_bcs(energy=0.0, hydrology=0.0))
         vl = wetting_front(N, n, zmin, zmax, sp.nu, col_offset)
-        zc, _ = O.grid(zmin, zmax, n)
+        zc, _ = grid_np(zmin, zmax, n)
         c = np.arange(col_offset, col_offset + N)
         T = 284.0 + 5.0 * zc[None, :] / (zmax - zmin) + 2.0 * (uhash(c, 1, n)[:, None] - 0.5)
         e = om.earth
@@ -149,7 +172,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
                            percol_bc={(O.FACE_TOP, O.COMP_HYDROLOGY): -0.5 * Ksat})
         vl = np.repeat((theta_r + 0.25 * (nu - theta_r))[:, None], n, axis=1)
         # a wetter band near the top so fluxes are not all tiny
-        zc, _ = O.grid(-2.56, 0.0, n)
+        zc, _ = grid_np(-2.56, 0.0, n)
         vl = vl + (0.5 * (nu - theta_r))[:, None] * sigmoid((zc[None, :] + 0.4) / 0.1)
         return Case(name, om, f64, N, vl=vl, ti=np.zeros((N, n)), col_offset=col_offset)
     if name in ("heat_dirichlet_f64", "heat_dirichlet_f32"):
@@ -162,7 +185,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         c = np.arange(N)
         vl = 0.1 + 0.35 * uhash(c[:, None], np.arange(n)[None, :] + 7, 1000)
         ti = np.where(uhash(c, 8, n)[:, None] < 0.3, 0.05 * uhash(c[:, None], np.arange(n)[None, :] + 99, 1000), 0.0)
-        zc, _ = O.grid(0.0, 1.0, n)
+        zc, _ = grid_np(0.0, 1.0, n)
         T = 285.0 + 3.0 * np.sin(6.0 * zc)[None, :] + uhash(c, 9, n)[:, None]
         e = om.earth
         tl = np.minimum(vl, sp.nu - ti)
@@ -205,7 +228,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         om = O.OracleModel(O.MODEL_COUPLED, n, -2.4, 0.0, soil=sp, vg=vg, bc=bc,
                            cf=O.default_cf(viscosity=True, impedance=True))
         c = np.arange(N)
-        zc, _ = O.grid(-2.4, 0.0, n)
+        zc, _ = grid_np(-2.4, 0.0, n)
         ph = 6.28 * uhash(c, 21, n)[:, None]
         ti = np.where(uhash(c, 22, n)[:, None] < 0.5,
                       0.06 * np.maximum(0.0, np.sin(3.0 * zc[None, :] + ph)), 0.0)

@@ -100,3 +100,22 @@ def test_host_mirror_domain_and_errors(pkg):
     assert np.allclose(zc, want, rtol=0, atol=4.5e-16)           # coupled.jl:198
     with pytest.raises(NotImplementedError):
         pkg.PrescribedAtmosForcing(u_atm=1.0)
+
+
+def test_bench_input_generation_executes_nothing_of_the_oracle():
+    """bench.py may use the oracle in its cpu_baseline leg only: building the synthetic
+    inputs of every workload must not even load the oracle library."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        "sys.argv = ['bench.py']\n"
+        "import bench, oracle_py\n"
+        "for w in bench.WORKLOADS:\n"
+        "    c = bench.build_case(w, 300, 7)\n"
+        "    assert c.vl is not None and c.vl.shape[0] == 300, w\n"
+        "assert oracle_py._lib is None, 'input generation loaded the oracle library'\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -402,3 +402,22 @@ def test_bottom_dirichlet_sign_quirk_and_flag():
     assert d_ref[0] == pytest.approx(-((-K) - (+K)) / dz, rel=1e-9)
     assert d_fix[0] == pytest.approx(0.0, abs=1e-9 * K / dz)
     assert np.allclose(d_ref[1:], d_fix[1:], rtol=0, atol=0)
+
+
+def test_input_generation_helpers_match_the_oracle():
+    """tests/parity_cases.py generates inputs (for the parity tests and for bench.py)
+    without executing the oracle: its numpy grid and its literal soil constants must be
+    bitwise what the oracle's functions give."""
+    import parity_cases as pc
+    for (zmin, zmax, n) in [(-1.28, 0.0, 64), (-2.56, 0.0, 128), (-2.0, 0.0, 20), (0.0, 1.0, 60),
+                            (-3.0, -0.5, 37), (-10.0, 0.0, 50), (-0.1, 0.0, 1), (-2.4, 0.0, 48)]:
+        for dt in (np.float64, np.float32):
+            zc, zf = pc.grid_np(zmin, zmax, n, dt)
+            wc, wf = O.grid(zmin, zmax, n, dt)
+            np.testing.assert_array_equal(zc, wc)
+            np.testing.assert_array_equal(zf, wf)
+    f = lambda name, *a: O.fn(name, np.float64)(*a)
+    k_solid = f("lho_k_solid", 0.0, 0.92, 7.7, 2.5, 0.25)
+    assert k_solid == pc.COUPLED_K_SOLID
+    assert f("lho_ksat_unfrozen", k_solid, 0.5, 0.57) == pc.COUPLED_KSAT_UNFROZEN
+    assert f("lho_ksat_frozen", k_solid, 0.5, 2.29) == pc.COUPLED_KSAT_FROZEN
