@@ -207,7 +207,9 @@ int lh_rhs(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* d
 
 /* lh_rhs plus, from the same pass over the state, this rank's stable-step bound
  * (the rule of lh_stable_dt) left in device memory (one FT value): the input of
- * the RCCL min all-reduce costs no second sweep over the columns. */
+ * the RCCL min all-reduce costs no second sweep over the columns.  With a
+ * communicator attached (lh_comm_init) that all-reduce is enqueued right behind
+ * the launch and the value is the global minimum. */
 int lh_rhs_stable_dt(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY,
                      double courant, void* dt_device_ft);
 
@@ -260,6 +262,36 @@ int lh_stable_dt(lh_ctx*, const lh_state* Y, const lh_state* Ya, double courant,
                  double* dt_host);
 int lh_stable_dt_device(lh_ctx*, const lh_state* Y, const lh_state* Ya, double courant,
                         void* dt_device_ft);
+
+/* ---- multi-GPU: block partition + the one collective ------------- */
+
+/* No counterpart in the reference (one column, one process, fixed user dt:
+ * src/Simulations/simulation.jl:34-70).  Columns are independent, so an ensemble
+ * of ncols_global columns is block-partitioned over ranks (one process and one
+ * context per GPU) with no halo and no data-path exchange.  The only collective
+ * of the path is the minimum of the ranks' stable-step bounds: ONE FT value,
+ * ncclAllReduce(count = 1, ncclMin) over RCCL/xGMI on the context's stream. */
+
+/* columns [*lo, *hi) owned by `rank` of `nranks` (the first ncols_global % nranks
+ * ranks own one more); per-column parameter and BC arrays partition the same way */
+int lh_block_range(int64_t ncols_global, int32_t rank, int32_t nranks, int64_t* lo, int64_t* hi);
+
+/* ncclGetUniqueId: fills LH_COMM_ID_BYTES bytes on ONE rank; the host ships them
+ * to the others (MPI_Bcast, a file, torch.distributed ...) before lh_comm_init */
+#define LH_COMM_ID_BYTES 128
+int lh_comm_unique_id(void* id_out);
+/* ncclCommInitRank on the context's device (collective: every rank calls it).
+ * While a communicator is attached, lh_rhs_stable_dt, lh_stable_dt_device and
+ * lh_stable_dt deliver the GLOBAL minimum over all ranks (the all-reduce is
+ * enqueued on the context's stream behind the local reduction: no host round
+ * trip); everything else stays rank-local. */
+int lh_comm_init(lh_ctx*, int32_t rank, int32_t nranks, const void* unique_id);
+int lh_comm_destroy(lh_ctx*);
+/* rank / nranks of the attached communicator (0 / 1 when there is none) */
+int lh_comm_info(const lh_ctx*, int32_t* rank, int32_t* nranks);
+/* in-place min all-reduce of one FT value in device memory over the attached
+ * communicator (no-op without one): for hosts that form their own step bound */
+int lh_allreduce_min(lh_ctx*, void* value_device_ft);
 
 /* ---- status / timing -------------------------------------------------------- */
 

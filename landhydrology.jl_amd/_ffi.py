@@ -25,6 +25,7 @@ LH_VAR_VARTHETA_L, LH_VAR_THETA_I, LH_VAR_RHOE_INT, LH_VAR_T = 0, 1, 2, 3
 LH_DIAG_K, LH_DIAG_PSI, LH_DIAG_KAPPA, LH_DIAG_T = 0, 1, 2, 3
 LH_MATH_FAST, LH_MATH_LIBM = 0, 1
 LH_PLACE_MOVE_INPUT = 1
+LH_COMM_ID_BYTES = 128
 LH_PC = dict(vg_n=0, vg_alpha=1, vg_theta_r=2, vg_Ksat=3, nu=4, S_s=5)
 LH_OK, LH_EINVAL, LH_ENODEVICE, LH_ENOMEM, LH_EMODEL, LH_ESTATE = 0, -1, -2, -3, -4, -5
 
@@ -88,6 +89,13 @@ SIGNATURES = {
                                     C.POINTER(C.c_float)]),
     "lh_stable_dt": (C.c_int, [_P, _P, _P, C.c_double, _DP]),
     "lh_stable_dt_device": (C.c_int, [_P, _P, _P, C.c_double, _P]),
+    "lh_block_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64)]),
+    "lh_comm_unique_id": (C.c_int, [_P]),
+    "lh_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "lh_comm_destroy": (C.c_int, [_P]),
+    "lh_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lh_allreduce_min": (C.c_int, [_P, _P]),
     "lh_get_status": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "lh_synchronize": (C.c_int, [_P]),
     "lh_timer_start": (C.c_int, [_P]),

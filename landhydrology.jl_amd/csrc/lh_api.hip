@@ -5,6 +5,8 @@
 #include "lh_launch.hpp"
 #include "lh_fastmath.hpp"
 
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -80,6 +82,9 @@ struct lh_ctx {
     std::vector<double> zc_host;
     std::string err;
     std::vector<lh_state*> states;
+    // the one collective of the path: min all-reduce of the stable-step bound
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
 };
 
 namespace {
@@ -102,6 +107,16 @@ int fail(lh_ctx* ctx, int code, const char* fmt, ...) {
             return fail(ctx, e_ == hipErrorOutOfMemory ? LH_ENOMEM : LH_ENODEVICE,           \
                         "%s failed: %s", #call, hipGetErrorString(e_));                      \
     } while (0)
+
+// In-place min all-reduce of one FT value over the attached communicator, enqueued on the
+// context's stream behind whatever produced the value (no host round trip).
+int allreduce_min(lh_ctx* c, void* value_device_ft) {
+    if (!c->comm) return LH_OK;
+    const ncclResult_t r = ncclAllReduce(value_device_ft, value_device_ft, 1,
+                                         c->cfg.dtype == LH_F64 ? ncclDouble : ncclFloat, ncclMin, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, LH_ENODEVICE, "ncclAllReduce(min) failed: %s", ncclGetErrorString(r));
+    return LH_OK;
+}
 
 // Uniform mesh of domain.jl:58-69: faces are the correctly rounded
 // zmin + k L / n (Julia ranges step in twice precision), centres are face
@@ -772,6 +787,10 @@ int lh_destroy(lh_ctx* c) {
     if (!c) return LH_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) {
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+    }
     while (!c->states.empty()) state_free(c, c->states.back());
     for (auto& a : c->arenas) (void)hipFree(a.base); // none should be left
     c->arenas.clear();
@@ -1009,9 +1028,11 @@ int lh_rhs_stable_dt(lh_ctx* c, double t, const lh_state* Y, const lh_state* Ya,
     if ((rc = check_state(c, dY, pm, "dY"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
-    return c->cfg.dtype == LH_F64
-               ? do_rhs<double>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft)
-               : do_rhs<float>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft);
+    rc = c->cfg.dtype == LH_F64
+             ? do_rhs<double>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft)
+             : do_rhs<float>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft);
+    if (rc) return rc;
+    return allreduce_min(c, dt_device_ft); // the global minimum when a communicator is attached
 }
 
 int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* out) {
@@ -1147,7 +1168,7 @@ int lh_stable_dt_device(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double
         launch_stable_dt<float>(P, planes_of<float>(Y), planes_of<float>(Ya), float(courant), d_out, any_percol(c), c->stream);
     }
     LH_HIP(c, hipGetLastError());
-    return LH_OK;
+    return allreduce_min(c, d_out); // the global minimum when a communicator is attached
 }
 
 int lh_stable_dt(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double courant, double* dt_host) {
@@ -1254,6 +1275,66 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
     if (ms_before) *ms_before = b0;
     if (ms_after) *ms_after = a0;
     return LH_OK;
+}
+
+int lh_block_range(int64_t ncols_global, int32_t rank, int32_t nranks, int64_t* lo, int64_t* hi) {
+    if (!lo || !hi || nranks < 1 || rank < 0 || rank >= nranks || ncols_global < nranks) return LH_EINVAL;
+    const int64_t q = ncols_global / nranks, r = ncols_global % nranks;
+    *lo = rank * q + (rank < r ? rank : r);
+    *hi = *lo + q + (rank < r ? 1 : 0);
+    return LH_OK;
+}
+
+int lh_comm_unique_id(void* id_out) {
+    static_assert(sizeof(ncclUniqueId) == LH_COMM_ID_BYTES, "LH_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    if (!id_out) return fail(nullptr, LH_EINVAL, "lh_comm_unique_id: NULL argument");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, LH_ENODEVICE, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return LH_OK;
+}
+
+int lh_comm_init(lh_ctx* c, int32_t rank, int32_t nranks, const void* unique_id) {
+    if (!c || !unique_id) return fail(c, LH_EINVAL, "lh_comm_init: NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LH_EINVAL, "lh_comm_init: rank %d outside [0, %d)", rank, nranks);
+    if (c->comm) return fail(c, LH_EINVAL, "lh_comm_init: a communicator is already attached (lh_comm_destroy first)");
+    (void)hipSetDevice(c->device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) return fail(c, LH_ENODEVICE, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, ncclGetErrorString(r));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return LH_OK;
+}
+
+int lh_comm_destroy(lh_ctx* c) {
+    if (!c) return LH_EINVAL;
+    if (!c->comm) return LH_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    const ncclResult_t r = ncclCommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_nranks = 1;
+    if (r != ncclSuccess) return fail(c, LH_ENODEVICE, "ncclCommDestroy failed: %s", ncclGetErrorString(r));
+    return LH_OK;
+}
+
+int lh_comm_info(const lh_ctx* c, int32_t* rank, int32_t* nranks) {
+    if (!c) return LH_EINVAL;
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (nranks) *nranks = c->comm ? c->comm_nranks : 1;
+    return LH_OK;
+}
+
+int lh_allreduce_min(lh_ctx* c, void* value_device_ft) {
+    if (!c || !value_device_ft) return fail(c, LH_EINVAL, "lh_allreduce_min: NULL argument");
+    (void)hipSetDevice(c->device);
+    return allreduce_min(c, value_device_ft);
 }
 
 int lh_timer_start(lh_ctx* c) {

@@ -9,7 +9,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from dataclasses import dataclass, field
 from typing import Optional
 
 import numpy as np
@@ -61,33 +60,6 @@ _DP = C.POINTER(C.c_double)
 class PerCol(C.Structure):
     _fields_ = [("vg_n", _DP), ("vg_alpha", _DP), ("vg_theta_r", _DP), ("vg_Ksat", _DP),
                 ("nu", _DP), ("S_s", _DP), ("bc_value", (_DP * 2) * 2)]
-
-
-# CLIMAParameters 0.1 values (K_therm and T_0 are pinned by the
-# reference's tests, the others are unpinned and therefore inputs everywhere).
-def default_earth() -> EarthParams:
-    return EarthParams(rho_liq=1000.0, rho_ice=916.7, cp_l=4181.0, cp_i=2100.0, T_0=273.16,
-                       LH_f0=2.8344e6 - 2.5008e6, K_therm=2.4e-2)
-
-
-def default_soil(**kw) -> SoilParams:
-    """src/SoilModel/parameters.jl:11-43 defaults (loam)."""
-    d = dict(nu=0.43, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.41,
-             rho_c_ds=2700.0, kappa_solid=3.97, rho_p=2700.0, kappa_sat_unfrozen=1.72,
-             kappa_sat_frozen=3.13, a=0.24, b=18.1, kappa_dry_parameter=0.053)
-    d.update(kw)
-    return SoilParams(**d)
-
-
-def default_vg(**kw) -> VGParams:
-    """SoilWaterParameterizations.jl:161-166 defaults (loam)."""
-    d = dict(n=1.56, alpha=3.6, theta_r=0.0, Ksat=2.9e-7)
-    d.update(kw)
-    return VGParams(**d)
-
-
-def default_cf(viscosity=False, impedance=False, gamma=2.64e-2, T_ref=288.0, Omega=7.0):
-    return CondFactors(int(viscosity), int(impedance), gamma, T_ref, Omega)
 
 
 def build(force: bool = False) -> str:
@@ -168,53 +140,53 @@ def fn(name: str, dtype):
     return getattr(lib(), f"{name}_{_sfx(dtype)}")
 
 
-@dataclass
-class OracleModel:
-    """A soil model description for the oracle: everything SoilModel(...) holds
-    (src/SoilModel/models.jl:90-135) as plain numbers."""
-    model: int
-    nlev: int
-    zmin: float
-    zmax: float
-    earth: EarthParams = field(default_factory=default_earth)
-    soil: SoilParams = field(default_factory=default_soil)
-    vg: VGParams = field(default_factory=default_vg)
-    cf: CondFactors = field(default_factory=default_cf)
-    # bc[(face, comp)] = (kind, value)
-    bc: dict = field(default_factory=dict)
-    consistent_bottom_sign: bool = False
-    # per-column overrides: name -> float64 array [ncols]; bc values via
-    # percol_bc[(face, comp)]
-    percol: dict = field(default_factory=dict)
-    percol_bc: dict = field(default_factory=dict)
+def _fill(struct_cls, obj):
+    """ctypes image of a plain parameter object (any object with the struct's field names)."""
+    return struct_cls(**{n: getattr(obj, n) for n, _ in struct_cls._fields_ if not n.startswith("pad")})
 
-    def c_model(self) -> Model:
-        m = Model()
-        m.model, m.nlev, m.zmin, m.zmax = self.model, self.nlev, self.zmin, self.zmax
-        m.earth, m.soil, m.vg, m.cf = self.earth, self.soil, self.vg, self.cf
-        for f in range(2):
-            for k in range(2):
-                kind, val = self.bc.get((f, k), (BC_NONE, 0.0))
-                m.bc[f][k].kind = kind
-                m.bc[f][k].value = val
-        m.consistent_bottom_sign = int(self.consistent_bottom_sign)
-        return m
 
-    def c_percol(self):
-        if not self.percol and not self.percol_bc:
-            return None, []
-        keep = []
-        pc = PerCol()
-        for name in ("vg_n", "vg_alpha", "vg_theta_r", "vg_Ksat", "nu", "S_s"):
-            if name in self.percol:
-                a = np.ascontiguousarray(self.percol[name], dtype=np.float64)
-                keep.append(a)
-                setattr(pc, name, a.ctypes.data_as(_DP))
-        for (f, k), v in self.percol_bc.items():
-            a = np.ascontiguousarray(v, dtype=np.float64)
+def as_c(obj):
+    """The ctypes struct of a plain parameter object (matched by class name), by reference
+    semantics ctypes applies to POINTER arguments; anything else passes through."""
+    cls = {"EarthParams": EarthParams, "SoilParams": SoilParams, "VGParams": VGParams,
+           "CondFactors": CondFactors}.get(type(obj).__name__)
+    if cls is None or isinstance(obj, C.Structure):
+        return obj
+    return _fill(cls, obj)
+
+
+def c_model(om) -> Model:
+    """The C image of a model description: any object with the attributes of
+    tests/case_model.CaseModel (model, nlev, zmin, zmax, earth, soil, vg, cf, bc,
+    consistent_bottom_sign)."""
+    m = Model()
+    m.model, m.nlev, m.zmin, m.zmax = om.model, om.nlev, om.zmin, om.zmax
+    m.earth, m.soil = _fill(EarthParams, om.earth), _fill(SoilParams, om.soil)
+    m.vg, m.cf = _fill(VGParams, om.vg), _fill(CondFactors, om.cf)
+    for f in range(2):
+        for k in range(2):
+            kind, val = om.bc.get((f, k), (BC_NONE, 0.0))
+            m.bc[f][k].kind = kind
+            m.bc[f][k].value = val
+    m.consistent_bottom_sign = int(om.consistent_bottom_sign)
+    return m
+
+
+def c_percol(om):
+    if not om.percol and not om.percol_bc:
+        return None, []
+    keep = []
+    pc = PerCol()
+    for name in ("vg_n", "vg_alpha", "vg_theta_r", "vg_Ksat", "nu", "S_s"):
+        if name in om.percol:
+            a = np.ascontiguousarray(om.percol[name], dtype=np.float64)
             keep.append(a)
-            pc.bc_value[f][k] = a.ctypes.data_as(_DP)
-        return pc, keep
+            setattr(pc, name, a.ctypes.data_as(_DP))
+    for (f, k), v in om.percol_bc.items():
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        keep.append(a)
+        pc.bc_value[f][k] = a.ctypes.data_as(_DP)
+    return pc, keep
 
 
 def _ptr(a: Optional[np.ndarray], ft):
@@ -246,7 +218,7 @@ def grid(zmin, zmax, n, dtype=np.float64):
     return zc, zf
 
 
-def rhs(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None, nthreads=1):
+def rhs(om, vl=None, ti=None, rhoe=None, T_aux=None, nthreads=1):
     """rhs!(dY, Y, Ya, t) for a batch.  Inputs are [ncols, nlev] arrays (any
     strides, all the same).  Returns dict of tendencies."""
     ref = vl if vl is not None else rhoe
@@ -267,8 +239,8 @@ def rhs(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None, nthreads=1):
     if om.model != MODEL_RICHARDS:
         d_re = np.empty_like(ref)
         out["rhoe"] = d_re
-    m = om.c_model()
-    pc, keep = om.c_percol()
+    m = c_model(om)
+    pc, keep = c_percol(om)
     rc = fn("lho_rhs", dtype)(C.byref(m), C.byref(pc) if pc is not None else None, ncols,
                               _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft), _ptr(T_aux, ft),
                               _ptr(d_vl, ft), _ptr(d_ti, ft), _ptr(d_re, ft), ls, cs, nthreads)
@@ -278,14 +250,14 @@ def rhs(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None, nthreads=1):
     return out
 
 
-def diagnostics(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None):
+def diagnostics(om, vl=None, ti=None, rhoe=None, T_aux=None):
     ref = vl if vl is not None else rhoe
     dtype = ref.dtype
     ft = _ft(dtype)
     ls, cs = _strides(ref)
     K, psi, T, kap = (np.empty_like(ref) for _ in range(4))
-    m = om.c_model()
-    pc, keep = om.c_percol()
+    m = c_model(om)
+    pc, keep = c_percol(om)
     rc = fn("lho_diagnostics", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
                                       ref.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
                                       _ptr(T_aux, ft), _ptr(K, ft), _ptr(psi, ft), _ptr(T, ft),
@@ -296,7 +268,7 @@ def diagnostics(om: OracleModel, vl=None, ti=None, rhoe=None, T_aux=None):
     return dict(K=K, psi=psi, T=T, kappa=kap)
 
 
-def ssprk33(om: OracleModel, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None, t0=0.0,
+def ssprk33(om, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None, t0=0.0,
             bc_stage_values=None, nthreads=1):
     """Advance the state arrays IN PLACE by nsteps fixed-dt SSPRK33 steps."""
     ref = vl if vl is not None else rhoe
@@ -307,8 +279,8 @@ def ssprk33(om: OracleModel, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None
     if bc_stage_values is not None:
         bcv = np.ascontiguousarray(bc_stage_values, dtype=np.float64)
         assert bcv.shape == (nsteps, 3, 2, 2)
-    m = om.c_model()
-    pc, keep = om.c_percol()
+    m = c_model(om)
+    pc, keep = c_percol(om)
     rc = fn("lho_ssprk33", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
                                   ref.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
                                   _ptr(T_aux, ft), ls, cs, float(t0), float(dt), int(nsteps),
@@ -318,12 +290,12 @@ def ssprk33(om: OracleModel, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None
         raise ValueError(f"oracle ssprk33 failed (code {rc})")
 
 
-def stable_dt(om: OracleModel, vl, ti, rhoe=None, courant=0.5, T_aux=None):
+def stable_dt(om, vl, ti, rhoe=None, courant=0.5, T_aux=None):
     dtype = vl.dtype
     ft = _ft(dtype)
     ls, cs = _strides(vl)
-    m = om.c_model()
-    pc, keep = om.c_percol()
+    m = c_model(om)
+    pc, keep = c_percol(om)
     r = fn("lho_stable_dt", dtype)(C.byref(m), C.byref(pc) if pc is not None else None,
                                    vl.shape[0], _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft),
                                    _ptr(T_aux, ft), ls, cs, float(courant))

@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import case_model as M  # noqa: E402
 import parity_cases as pc  # noqa: E402
 
 CASES = {  # name -> (ncols, nsteps)
@@ -50,8 +51,8 @@ def build(name):
         O.ssprk33(case.om, dt, nsteps, vl=vl, ti=ti, rhoe=re, T_aux=case.T_aux)
         out["dt"] = dt
         for k, v in (("vl", vl), ("ti", ti), ("rhoe", re)):
-            if v is not None and not (case.om.model == O.MODEL_HEAT and k != "rhoe") \
-                    and not (case.om.model == O.MODEL_RICHARDS and k == "rhoe"):
+            if v is not None and not (case.om.model == M.MODEL_HEAT and k != "rhoe") \
+                    and not (case.om.model == M.MODEL_RICHARDS and k == "rhoe"):
                 out["end_" + k] = v
     return out
 

@@ -1,7 +1,8 @@
 """Shared parity machinery: synthetic cases, a runner for the HIP
 path THROUGH THE C ABI, a runner for the CPU oracle, and the tolerance model.
 
-Test infrastructure: imports the oracle; never imported by the product.
+Test infrastructure, never imported by the product.  The oracle is imported lazily by the
+checker legs only (see `O`).
 
 Tolerance model (why not one global rtol): a tendency is a difference of face
 fluxes, each a product of a conductivity and a head gradient, so agreement
@@ -25,7 +26,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import oracle_py as O  # noqa: E402
+import case_model as M  # noqa: E402  (plain descriptions; imports nothing from oracle/)
+
+
+class _LazyOracle:
+    """`O.rhs`, `O.ssprk33`, ... -- oracle/oracle_py.py, imported on first use only: building
+    a case or running the HIP path never loads (or even imports) the oracle; the checker legs
+    (run_oracle_rhs, the tolerance model) do."""
+
+    def __getattr__(self, name):
+        import oracle_py
+        return getattr(oracle_py, name)
+
+
+O = _LazyOracle()
 
 SEED = 0x4C485944524F  # "LHYDRO"
 
@@ -49,7 +63,7 @@ def uhash(c: np.ndarray, i, n: int, seed: int = SEED) -> np.ndarray:
 @dataclass
 class Case:
     name: str
-    om: O.OracleModel
+    om: M.CaseModel
     dtype: type
     ncols: int
     # host arrays [ncols, nlev] (level-fastest, like parent(field)); None = unused
@@ -72,11 +86,11 @@ COUPLED_KSAT_FROZEN = 4.014403985110721
 def coupled_soil():
     """test/SoilModel/coupled.jl:3-32."""
     nu = 0.5
-    sp = O.default_soil(nu=nu, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.92,
+    sp = M.default_soil(nu=nu, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.92,
                         rho_c_ds=(1 - nu) * 1.926e06, kappa_solid=COUPLED_K_SOLID,
                         kappa_sat_unfrozen=COUPLED_KSAT_UNFROZEN,
                         kappa_sat_frozen=COUPLED_KSAT_FROZEN)
-    vg = O.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
+    vg = M.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
     return sp, vg
 
 
@@ -98,11 +112,11 @@ def grid_np(zmin, zmax, n, dtype=np.float64):
 
 def _flux_bcs(energy=None, hydrology=None):
     bc = {}
-    for f in (O.FACE_BOTTOM, O.FACE_TOP):
+    for f in (M.FACE_BOTTOM, M.FACE_TOP):
         if energy is not None:
-            bc[(f, O.COMP_ENERGY)] = (O.BC_FLUX, energy)
+            bc[(f, M.COMP_ENERGY)] = (M.BC_FLUX, energy)
         if hydrology is not None:
-            bc[(f, O.COMP_HYDROLOGY)] = (O.BC_FLUX, hydrology)
+            bc[(f, M.COMP_HYDROLOGY)] = (M.BC_FLUX, hydrology)
     return bc
 
 
@@ -126,16 +140,16 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
     if name == "c1_dirichlet_f64":
         # C1: 1 column, n=64, zlim=(-1.28,0), loam, Dirichlet 0.35 top / 0.20 bottom
         n, N = 64, ncols or 1
-        bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.35),
-              (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.20)}
-        om = O.OracleModel(O.MODEL_RICHARDS, n, -1.28, 0.0, bc=bc)
+        bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.35),
+              (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.20)}
+        om = M.CaseModel(M.MODEL_RICHARDS, n, -1.28, 0.0, bc=bc)
         return Case(name, om, f64, N, vl=np.full((N, n), 0.20), ti=np.zeros((N, n)))
     if name in ("c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128"):
         n = 128 if name.startswith("c4") else 64
         zmin = -2.56 if n == 128 else -1.28
         N = ncols or 1000
         dt = f32 if name.endswith("f32") else f64
-        om = O.OracleModel(O.MODEL_RICHARDS, n, zmin, 0.0, bc=_flux_bcs(hydrology=0.0))
+        om = M.CaseModel(M.MODEL_RICHARDS, n, zmin, 0.0, bc=_flux_bcs(hydrology=0.0))
         vl = wetting_front(N, n, zmin, 0.0, om.soil.nu, col_offset).astype(dt)
         return Case(name, om, dt, N, vl=vl, ti=np.zeros((N, n), dt), col_offset=col_offset)
     if name in ("c3_coupled_f32", "coupled_f64_small", "c3_coupled_f64"):
@@ -144,7 +158,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         dt = f32 if name.endswith("f32") else f64
         sp, vg = coupled_soil()
         zmin, zmax = -1.28, 0.0
-        om = O.OracleModel(O.MODEL_COUPLED, n, zmin, zmax, soil=sp, vg=vg,
+        om = M.CaseModel(M.MODEL_COUPLED, n, zmin, zmax, soil=sp, vg=vg,
                            bc=_flux_bcs(energy=0.0, hydrology=0.0))
         vl = wetting_front(N, n, zmin, zmax, sp.nu, col_offset)
         zc, _ = grid_np(zmin, zmax, n)
@@ -164,12 +178,12 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         Ksat = 10.0 ** (-7.0 + 3.0 * uhash(c, 4, n))
         theta_r = 0.08 * uhash(c, 5, n)
         nu = 0.3 + 0.25 * uhash(c, 6, n)
-        bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_FLUX, 0.0),
-              (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)}
-        om = O.OracleModel(O.MODEL_RICHARDS, n, -2.56, 0.0, bc=bc,
+        bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_FLUX, 0.0),
+              (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)}
+        om = M.CaseModel(M.MODEL_RICHARDS, n, -2.56, 0.0, bc=bc,
                            percol=dict(vg_n=vg_n, vg_alpha=alpha, vg_Ksat=Ksat, vg_theta_r=theta_r,
                                        nu=nu),
-                           percol_bc={(O.FACE_TOP, O.COMP_HYDROLOGY): -0.5 * Ksat})
+                           percol_bc={(M.FACE_TOP, M.COMP_HYDROLOGY): -0.5 * Ksat})
         vl = np.repeat((theta_r + 0.25 * (nu - theta_r))[:, None], n, axis=1)
         # a wetter band near the top so fluxes are not all tiny
         zc, _ = grid_np(-2.56, 0.0, n)
@@ -179,9 +193,9 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         n, N = 60, ncols or 300
         dt = f32 if name.endswith("f32") else f64
         sp, _ = coupled_soil()
-        bc = {(O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 280.0),
-              (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_DIRICHLET, 290.0)}
-        om = O.OracleModel(O.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
+        bc = {(M.FACE_TOP, M.COMP_ENERGY): (M.BC_DIRICHLET, 280.0),
+              (M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_DIRICHLET, 290.0)}
+        om = M.CaseModel(M.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
         c = np.arange(N)
         vl = 0.1 + 0.35 * uhash(c[:, None], np.arange(n)[None, :] + 7, 1000)
         ti = np.where(uhash(c, 8, n)[:, None] < 0.3, 0.05 * uhash(c[:, None], np.arange(n)[None, :] + 99, 1000), 0.0)
@@ -198,12 +212,12 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         n, N = 37, ncols or 515   # ragged sizes on purpose
         dt = f32 if name.endswith("f32") else f64
         sp, vg = coupled_soil()
-        bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.47),
-              (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0),
-              (O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 275.0),
-              (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_FLUX, 0.05)}
-        om = O.OracleModel(O.MODEL_COUPLED, n, -3.0, -0.5, soil=sp, vg=vg, bc=bc,
-                           cf=O.default_cf(viscosity=True, impedance=True))
+        bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.47),
+              (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0),
+              (M.FACE_TOP, M.COMP_ENERGY): (M.BC_DIRICHLET, 275.0),
+              (M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_FLUX, 0.05)}
+        om = M.CaseModel(M.MODEL_COUPLED, n, -3.0, -0.5, soil=sp, vg=vg, bc=bc,
+                           cf=M.default_cf(viscosity=True, impedance=True))
         c = np.arange(N)[:, None]
         lev = np.arange(n)[None, :]
         ti = np.where(uhash(c, 11, 1) < 0.5, 0.12 * uhash(c, lev + 13, 1000), 0.0)
@@ -221,12 +235,12 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         n, N = 48, ncols or 200
         dt = f32 if name.endswith("f32") else f64
         sp, vg = coupled_soil()
-        bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.42),
-              (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0),
-              (O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 276.0),
-              (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_FLUX, 0.05)}
-        om = O.OracleModel(O.MODEL_COUPLED, n, -2.4, 0.0, soil=sp, vg=vg, bc=bc,
-                           cf=O.default_cf(viscosity=True, impedance=True))
+        bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.42),
+              (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0),
+              (M.FACE_TOP, M.COMP_ENERGY): (M.BC_DIRICHLET, 276.0),
+              (M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_FLUX, 0.05)}
+        om = M.CaseModel(M.MODEL_COUPLED, n, -2.4, 0.0, soil=sp, vg=vg, bc=bc,
+                           cf=M.default_cf(viscosity=True, impedance=True))
         c = np.arange(N)
         zc, _ = grid_np(-2.4, 0.0, n)
         ph = 6.28 * uhash(c, 21, n)[:, None]
@@ -241,10 +255,10 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
         return Case(name, om, dt, N, vl=vl.astype(dt), ti=ti.astype(dt), rhoe=rhoe.astype(dt))
     if name == "richards_viscosity_f64":
         n, N = 50, ncols or 130
-        om = O.OracleModel(O.MODEL_RICHARDS, n, -10.0, 0.0,
-                           bc={(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_FLUX, -1e-7),
-                               (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.40)},
-                           cf=O.default_cf(viscosity=True))
+        om = M.CaseModel(M.MODEL_RICHARDS, n, -10.0, 0.0,
+                           bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_FLUX, -1e-7),
+                               (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.40)},
+                           cf=M.default_cf(viscosity=True))
         c = np.arange(N)[:, None]
         lev = np.arange(n)[None, :]
         vl = 0.1 + 0.3 * uhash(c, lev, 1000)
@@ -253,9 +267,9 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
     if name == "single_cell_f64":
         # n = 1: both faces are boundary faces
         N = ncols or 70
-        om = O.OracleModel(O.MODEL_RICHARDS, 1, -0.1, 0.0,
-                           bc={(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.3),
-                               (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)})
+        om = M.CaseModel(M.MODEL_RICHARDS, 1, -0.1, 0.0,
+                           bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.3),
+                               (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)})
         vl = (0.1 + 0.3 * uhash(np.arange(N), 0, 1))[:, None]
         return Case(name, om, np.float64, N, vl=vl, ti=np.zeros((N, 1)))
     raise KeyError(name)
@@ -485,8 +499,8 @@ def tendency_tolerance(case: Case, Cw: float = 16.0):
     dz = (om.zmax - om.zmin) / n
     zc, _ = O.grid(om.zmin, om.zmax, n)
     zc = zc[None, :]
-    water = om.model != O.MODEL_HEAT
-    heat = om.model != O.MODEL_RICHARDS
+    water = om.model != M.MODEL_HEAT
+    heat = om.model != M.MODEL_RICHARDS
     e = om.earth
     rhocp_l = e.cp_l * e.rho_liq
     E = rhocp_l * (T - e.T_0) * K
@@ -512,35 +526,35 @@ def tendency_tolerance(case: Case, Cw: float = 16.0):
                                 + np.abs(Eb) * (abs_h[:, 1:] + abs_h[:, :-1]) / dz
                                 + eps * np.abs(Eb * g))
     # boundary faces: evaluate the face closures with the oracle
-    for face, ci, k in ((O.FACE_BOTTOM, 0, 0), (O.FACE_TOP, n - 1, n)):
-        kh, vh = om.bc.get((face, O.COMP_HYDROLOGY), (O.BC_NONE, 0.0))
-        ke, ve = om.bc.get((face, O.COMP_ENERGY), (O.BC_NONE, 0.0))
-        pch = om.percol_bc.get((face, O.COMP_HYDROLOGY))
+    for face, ci, k in ((M.FACE_BOTTOM, 0, 0), (M.FACE_TOP, n - 1, n)):
+        kh, vh = om.bc.get((face, M.COMP_HYDROLOGY), (M.BC_NONE, 0.0))
+        ke, ve = om.bc.get((face, M.COMP_ENERGY), (M.BC_NONE, 0.0))
+        pch = om.percol_bc.get((face, M.COMP_HYDROLOGY))
         vh = np.asarray(pch if pch is not None else vh, dtype=np.float64) + np.zeros(N)
         dzb = dz / 2
         vl_f = case.vl.copy()
         re_f = None if case.rhoe is None else case.rhoe.copy()
-        if water and kh == O.BC_DIRICHLET:
+        if water and kh == M.BC_DIRICHLET:
             vl_f[:, ci] = vh.astype(case.dtype)
         fc = Case("face", om, case.dtype, N, vl=vl_f, ti=case.ti, rhoe=re_f, T_aux=case.T_aux)
         dgf = O.diagnostics(om, vl_f, case.ti, case.rhoe, case.T_aux)
         tf = closure_tolerances(fc, dgf, Cw)
         Kf, psif, kapf = f8(dgf["K"])[:, ci], f8(dgf["psi"])[:, ci], f8(dgf["kappa"])[:, ci]
         if water:
-            if kh == O.BC_FLUX:
+            if kh == M.BC_FLUX:
                 dFw[:, k] = eps * np.abs(vh)
-            elif kh == O.BC_FREE_DRAINAGE:
+            elif kh == M.BC_FREE_DRAINAGE:
                 dFw[:, k] = tol["K"][:, ci]
-            elif kh == O.BC_DIRICHLET:
+            elif kh == M.BC_DIRICHLET:
                 gb = (psif - psi[:, ci] + dzb) / dzb
                 gb2 = (psif - psi[:, ci] - dzb) / dzb
                 gmax = np.maximum(np.abs(gb), np.abs(gb2))
                 dFw[:, k] = (tf["K"][:, ci] * gmax + Kf * (tf["psi"][:, ci] + tol["psi"][:, ci]) / dzb
                              + eps * Kf * gmax)
         if heat:
-            if ke == O.BC_FLUX:
+            if ke == M.BC_FLUX:
                 dFe[:, k] = eps * abs(ve)
-            elif ke == O.BC_DIRICHLET:
+            elif ke == M.BC_DIRICHLET:
                 gTb = (ve - T[:, ci]) / dzb
                 dFe[:, k] = (tf["kappa"][:, ci] * np.abs(gTb) + kapf * (tol["T"][:, ci] + eps * abs(ve)) / dzb
                              + eps * np.abs(kapf * gTb))

@@ -49,7 +49,7 @@ def test_closures_match_oracle(name):
     want = pc.O.diagnostics(case.om, case.vl, case.ti, case.rhoe, case.T_aux)
     tol = pc.closure_tolerances(case, want, cw(case))
     for k in ("K", "psi", "T", "kappa"):
-        if case.om.model == pc.O.MODEL_RICHARDS and k in ("T", "kappa"):
+        if case.om.model == pc.M.MODEL_RICHARDS and k in ("T", "kappa"):
             continue
         err = np.abs(got[k].astype(np.float64) - want[k].astype(np.float64))
         assert np.all(err <= tol[k]), (k, float(np.max(err / tol[k])))
@@ -101,7 +101,7 @@ def test_invalid_models_raise_like_the_reference():
         with pytest.raises(F.ModelError):
             g.rhs(Y, Ya, dY)
     case = pc.make_case("c2_richards_f64", ncols=8)
-    case.om.bc[(pc.O.FACE_TOP, pc.O.COMP_ENERGY)] = (pc.O.BC_DIRICHLET, 280.0)
+    case.om.bc[(pc.M.FACE_TOP, pc.M.COMP_ENERGY)] = (pc.M.BC_DIRICHLET, 280.0)
     with pc.GpuModel(case) as g:
         Y, Ya = g.prognostic_and_aux()
         dY = g.state(0)

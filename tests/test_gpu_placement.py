@@ -12,6 +12,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import case_model as M
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
@@ -21,10 +22,10 @@ O = pc.O
 def _fields(g, st, case):
     F, m = g.F, case.om.model
     out = {}
-    if m != O.MODEL_HEAT:
+    if m != M.MODEL_HEAT:
         out["vl"] = g.download(st, F.LH_VAR_VARTHETA_L)
         out["ti"] = g.download(st, F.LH_VAR_THETA_I)
-    if m != O.MODEL_RICHARDS:
+    if m != M.MODEL_RICHARDS:
         out["rhoe"] = g.download(st, F.LH_VAR_RHOE_INT)
     return out
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import __graft_entry__ as g
+import case_model as M
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
@@ -154,10 +155,10 @@ def test_richards_sand_alternate_bc_through_simulation(lh):
     lh.run(sim)
     vl = sim.integrator.sol.u[-1]["ϑ_l"]
     O = pc.O
-    om = O.OracleModel(O.MODEL_RICHARDS, 150, -1.5, 0.0, soil=O.default_soil(nu=0.287, S_s=1e-3),
-                       vg=O.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075),
-                       bc={(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.267),
-                           (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)})
+    om = M.CaseModel(M.MODEL_RICHARDS, 150, -1.5, 0.0, soil=M.default_soil(nu=0.287, S_s=1e-3),
+                       vg=M.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075),
+                       bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.267),
+                           (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)})
     w = np.full((1, 150), 0.1)
     O.ssprk33(om, 0.25, 1200, vl=w, ti=np.zeros((1, 150)))
     assert np.max(np.abs(vl - w) / w) < 1e-6                                 # north star
@@ -219,7 +220,7 @@ def test_host_evaluated_top_flux_from_interior_values(lh):
     lh.make_rhs(model)(dY, Y, Ya, 0.0)
     import dataclasses
     O = pc.O
-    om = dataclasses.replace(case.om, percol_bc={(O.FACE_TOP, O.COMP_HYDROLOGY): evap})
+    om = dataclasses.replace(case.om, percol_bc={(M.FACE_TOP, M.COMP_HYDROLOGY): evap})
     want = pc.run_oracle_rhs(dataclasses.replace(case, om=om))
     pc.assert_tendencies_close(case, {"vl": dY.soil.ϑ_l, "ti": dY.soil.θ_i}, want, 4.0)
 

@@ -12,6 +12,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import case_model as M
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
@@ -27,10 +28,10 @@ SEGS = [b"seg=8,persist=0", b"seg=5,persist=0", b"seg=1,persist=0", b"seg=0,pers
 def _fields(g, st, case):
     F, m = g.F, case.om.model
     out = {}
-    if m != O.MODEL_HEAT:
+    if m != M.MODEL_HEAT:
         out["vl"] = g.download(st, F.LH_VAR_VARTHETA_L)
         out["ti"] = g.download(st, F.LH_VAR_THETA_I)
-    if m != O.MODEL_RICHARDS:
+    if m != M.MODEL_RICHARDS:
         out["rhoe"] = g.download(st, F.LH_VAR_RHOE_INT)
     return out
 
@@ -45,7 +46,7 @@ def _run(case, tune, nsteps, dt):
         res = {"rhs": _fields(g, dY, case)}
         import torch
         dev = torch.zeros(1, device="cuda", dtype=torch.float64 if case.dtype == np.float64 else torch.float32)
-        if case.om.model != O.MODEL_HEAT or True:
+        if case.om.model != M.MODEL_HEAT or True:
             F.check(L.lh_rhs_stable_dt(g.ctx, 0.0, Y, Ya, dY, 0.4, C.c_void_p(dev.data_ptr())), g.ctx)
             F.check(L.lh_synchronize(g.ctx), g.ctx)
             res["rhs4"] = _fields(g, dY, case)

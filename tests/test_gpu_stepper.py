@@ -14,6 +14,7 @@ import math
 import numpy as np
 import pytest
 
+import case_model as M
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
@@ -31,10 +32,10 @@ def gpu_steps(case, dt, nsteps, bcv=None, math_mode=None):
         F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, dt, nsteps, p), g.ctx)
         out = {}
         m = case.om.model
-        if m != O.MODEL_HEAT:
+        if m != M.MODEL_HEAT:
             out["vl"] = g.download(Y, F.LH_VAR_VARTHETA_L)
             out["ti"] = g.download(Y, F.LH_VAR_THETA_I)
-        if m != O.MODEL_RICHARDS:
+        if m != M.MODEL_RICHARDS:
             out["rhoe"] = g.download(Y, F.LH_VAR_RHOE_INT)
         assert g.status() == 0
         return out
@@ -45,9 +46,9 @@ def cpu_steps(case, dt, nsteps, bcv=None):
     vl, ti, re = cp(case.vl), cp(case.ti), cp(case.rhoe)
     O.ssprk33(case.om, dt, nsteps, vl=vl, ti=ti, rhoe=re, T_aux=case.T_aux, bc_stage_values=bcv)
     out = {}
-    if case.om.model != O.MODEL_HEAT:
+    if case.om.model != M.MODEL_HEAT:
         out["vl"], out["ti"] = vl, ti
-    if case.om.model != O.MODEL_RICHARDS:
+    if case.om.model != M.MODEL_RICHARDS:
         out["rhoe"] = re
     return out
 
@@ -106,8 +107,8 @@ def test_time_dependent_dirichlet_stage_values():
     t = dt * np.arange(nsteps)
     ts = np.stack([t, t + dt, t + dt / 2], axis=1)
     bcv = np.zeros((nsteps, 3, 2, 2))
-    bcv[:, :, O.FACE_BOTTOM, O.COMP_ENERGY] = 290.0 + 5.0 * np.cos(2 * math.pi * ts / (40 * dt))
-    bcv[:, :, O.FACE_TOP, O.COMP_ENERGY] = 280.0 - 3.0 * np.sin(2 * math.pi * ts / (25 * dt))
+    bcv[:, :, M.FACE_BOTTOM, M.COMP_ENERGY] = 290.0 + 5.0 * np.cos(2 * math.pi * ts / (40 * dt))
+    bcv[:, :, M.FACE_TOP, M.COMP_ENERGY] = 280.0 - 3.0 * np.sin(2 * math.pi * ts / (25 * dt))
     got = gpu_steps(case, dt, nsteps, bcv)
     want = cpu_steps(case, dt, nsteps, bcv)
     assert_state_close(case, got, want, 1e-11)
@@ -157,13 +158,13 @@ def expected_equilibrium(z, z_interface, nu, S_s=1e-3, alpha=2.6, n=2.0, m=0.5):
 
 def test_heat_analytic_on_device():
     """test/SoilModel/heat_test_interface.jl:1-100 (MSE < 1e-6 vs the closed form)."""
-    sp = O.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
+    sp = M.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
                         rho_c_ds=0.43314518988433487, kappa_solid=8.0, kappa_sat_unfrozen=0.57,
                         kappa_sat_frozen=2.29)
     n, dt, tf, A, omega = 60, 1e-4, 2.0, 5.0, 2 * math.pi
-    bc = {(O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 0.0),
-          (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_DIRICHLET, A)}
-    om = O.OracleModel(O.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
+    bc = {(M.FACE_TOP, M.COMP_ENERGY): (M.BC_DIRICHLET, 0.0),
+          (M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_DIRICHLET, A)}
+    om = M.CaseModel(M.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
     e = om.earth
     rho_c_s = sp.rho_c_ds
     rhoe0 = rho_c_s * (0.0 - e.T_0)
@@ -174,7 +175,7 @@ def test_heat_analytic_on_device():
     t = dt * np.arange(nsteps)
     ts = np.stack([t, t + dt, t + dt / 2], axis=1)
     bcv = np.zeros((nsteps, 3, 2, 2))
-    bcv[:, :, O.FACE_BOTTOM, O.COMP_ENERGY] = A * np.cos(omega * ts)
+    bcv[:, :, M.FACE_BOTTOM, M.COMP_ENERGY] = A * np.cos(omega * ts)
     got = gpu_steps(case, dt, nsteps, bcv)
     z, _ = O.grid(0.0, 1.0, n)
     s = math.sqrt(omega / 2) * (1 + 1j)
@@ -195,7 +196,7 @@ def test_coupled_equilibrium_on_device():
     sp, vg = pc.coupled_soil()
     n, dt = 20, 20.0
     nsteps = int(60 * 60 * 24 * 32 / dt)
-    om = O.OracleModel(O.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg,
+    om = M.CaseModel(M.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg,
                        bc=pc._flux_bcs(energy=0.0, hydrology=0.0))
     z, _ = O.grid(-2.0, 0.0, n)
     e = om.earth
@@ -223,11 +224,11 @@ def test_coupled_equilibrium_on_device():
 def test_richards_equilibrium_on_device():
     """test/SoilModel/richards_equation.jl:1-95 in full: 36 days at dt = 100 s on the
     device, the reference's assertion as written (:94)."""
-    sp = O.default_soil(nu=0.495, S_s=1e-3)
-    vg = O.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
+    sp = M.default_soil(nu=0.495, S_s=1e-3)
+    vg = M.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
     n, dt = 50, 100.0
     nsteps = int(60 * 60 * 24 * 36 / dt)
-    om = O.OracleModel(O.MODEL_RICHARDS, n, -10.0, 0.0, soil=sp, vg=vg,
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -10.0, 0.0, soil=sp, vg=vg,
                        bc=pc._flux_bcs(hydrology=0.0))
     z, _ = O.grid(-10.0, 0.0, n)
     case = pc.Case("richards_eq", om, np.float64, 1, vl=np.full((1, n), 0.494),
@@ -243,11 +244,11 @@ def test_sand_infiltration_on_device():
     """test/SoilModel/richards_equation.jl:98-173 setup (Dirichlet top, free
     drainage bottom), 10 of the 48 minutes; the reference's comparison data is a
     download and unavailable offline, so the check is parity with the oracle."""
-    sp = O.default_soil(nu=0.287, S_s=1e-3)
-    vg = O.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075)
-    bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.267),
-          (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)}
-    om = O.OracleModel(O.MODEL_RICHARDS, 150, -1.5, 0.0, soil=sp, vg=vg, bc=bc)
+    sp = M.default_soil(nu=0.287, S_s=1e-3)
+    vg = M.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075)
+    bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.267),
+          (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)}
+    om = M.CaseModel(M.MODEL_RICHARDS, 150, -1.5, 0.0, soil=sp, vg=vg, bc=bc)
     case = pc.Case("sand", om, np.float64, 4, vl=np.full((4, 150), 0.1), ti=np.zeros((4, 150)))
     got = gpu_steps(case, 0.25, 2400)
     want = cpu_steps(case, 0.25, 2400)

@@ -7,21 +7,22 @@ import math
 import numpy as np
 import pytest
 
+import case_model as M
 import oracle_py as O
 
 F32, F64 = np.float32, np.float64
-EARTH = O.default_earth()
+EARTH = M.default_earth()
 
 
 def call(name, dtype, *args):
-    return O.fn(name, dtype)(*args)
+    return O.fn(name, dtype)(*[O.as_c(a) for a in args])
 
 
 # ---------------------------------------------------------------- K1 (Float32)
 # test/SoilModel/test_water_parameterizations.jl:1-63
 class TestWaterParams:
     FT = F32
-    vg = O.default_vg(theta_r=float(np.float32(0.2)))
+    vg = M.default_vg(theta_r=float(np.float32(0.2)))
     nu = np.float32(0.4)
     S_s = np.float32(1e-2)
 
@@ -65,13 +66,13 @@ class TestWaterParams:
         assert np.allclose(k, [va, Ksat, Ksat], rtol=1e-5)
 
     def test_factors(self):  # :40-46
-        cf = O.default_cf(viscosity=True, impedance=True)
+        cf = M.default_cf(viscosity=True, impedance=True)
         assert call("lho_impedance_factor", F32, cf, F32(1.0)) == pytest.approx(1e-7, rel=1e-6)
         T = np.array([278.0, 288.0, 298.0], dtype=F32)
         got = [call("lho_viscosity_factor", F32, cf, t) for t in T]
         want = np.exp(F32(2.64e-2) * (T - F32(288.0)))
         assert np.allclose(got, want, rtol=1e-6)
-        none = O.default_cf()
+        none = M.default_cf()
         assert call("lho_impedance_factor", F32, none, F32(0.3)) == 1.0
         assert call("lho_viscosity_factor", F32, none, F32(300)) == 1.0
 
@@ -120,7 +121,7 @@ class TestHeatParams:
     def test_relative_saturation(self):  # :36
         assert call("lho_relative_saturation", F64, 0.25, 0.05, 0.4) == (0.25 + 0.05) / 0.4
 
-    SP = O.default_soil(nu=0.2, S_s=1e-3, nu_ss_om=0.1, nu_ss_gravel=0.1, nu_ss_quartz=0.1,
+    SP = M.default_soil(nu=0.2, S_s=1e-3, nu_ss_om=0.1, nu_ss_gravel=0.1, nu_ss_quartz=0.1,
                         rho_c_ds=0.0, kappa_solid=0.1, rho_p=1.0, kappa_sat_unfrozen=0.0,
                         kappa_sat_frozen=0.0)
 
@@ -159,7 +160,7 @@ class TestHeatParams:
         # heat_test_interface.jl:7 sets rho_c_ds = 0.43314518988433487 so that
         # kappa/rho_c_s == 1 for dry soil; that equals k_dry only for
         # K_therm = 0.024.
-        sp = O.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
+        sp = M.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
                             rho_c_ds=0.43314518988433487, kappa_solid=8.0,
                             kappa_sat_unfrozen=0.57, kappa_sat_frozen=2.29)
         assert call("lho_k_dry", F64, EARTH, sp) == 0.43314518988433487
@@ -182,20 +183,20 @@ def coupled_soil():
     k_solid = call("lho_k_solid", F64, 0.0, 0.92, 7.7, 2.5, 0.25)
     k_fr = call("lho_ksat_frozen", F64, k_solid, nu, 2.29)
     k_unf = call("lho_ksat_unfrozen", F64, k_solid, nu, 0.57)
-    sp = O.default_soil(nu=nu, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.92,
+    sp = M.default_soil(nu=nu, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.92,
                         rho_c_ds=(1 - nu) * 1.926e06, kappa_solid=k_solid,
                         kappa_sat_unfrozen=k_unf, kappa_sat_frozen=k_fr)
-    vg = O.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
+    vg = M.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
     return sp, vg
 
 
 def zero_flux_bcs(energy=True, hydrology=True):
     bc = {}
-    for f in (O.FACE_BOTTOM, O.FACE_TOP):
+    for f in (M.FACE_BOTTOM, M.FACE_TOP):
         if energy:
-            bc[(f, O.COMP_ENERGY)] = (O.BC_FLUX, 0.0)
+            bc[(f, M.COMP_ENERGY)] = (M.BC_FLUX, 0.0)
         if hydrology:
-            bc[(f, O.COMP_HYDROLOGY)] = (O.BC_FLUX, 0.0)
+            bc[(f, M.COMP_HYDROLOGY)] = (M.BC_FLUX, 0.0)
     return bc
 
 
@@ -204,7 +205,7 @@ def test_single_rhs_eval_default_ic():
     """test/SoilModel/coupled.jl:123-234 ("test default ic")."""
     sp, vg = coupled_soil()
     n = 20
-    om = O.OracleModel(O.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
+    om = M.CaseModel(M.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
     # default_initial_conditions, models.jl:147-162
     vl = np.full((1, n), 0.5 * sp.nu)
     ti = np.zeros((1, n))
@@ -229,14 +230,14 @@ def test_single_rhs_eval_default_ic():
 def test_heat_analytic():
     """test/SoilModel/heat_test_interface.jl:1-100: heat-only, Dirichlet T=0 top,
     T = 5 cos(2 pi t) bottom, n=60 on (0,1), dt=1e-4, t_f=2, MSE < 1e-6."""
-    sp = O.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
+    sp = M.default_soil(nu=0.495, nu_ss_gravel=0.1, nu_ss_om=0.1, nu_ss_quartz=0.1,
                         rho_c_ds=0.43314518988433487, kappa_solid=8.0, kappa_sat_unfrozen=0.57,
                         kappa_sat_frozen=2.29)
     n, dt, tf = 60, 1e-4, 2.0
     A, omega = 5.0, 2 * math.pi / 1.0
-    bc = {(O.FACE_TOP, O.COMP_ENERGY): (O.BC_DIRICHLET, 0.0),
-          (O.FACE_BOTTOM, O.COMP_ENERGY): (O.BC_DIRICHLET, A)}
-    om = O.OracleModel(O.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
+    bc = {(M.FACE_TOP, M.COMP_ENERGY): (M.BC_DIRICHLET, 0.0),
+          (M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_DIRICHLET, A)}
+    om = M.CaseModel(M.MODEL_HEAT, n, 0.0, 1.0, soil=sp, bc=bc)
     vl = np.zeros((1, n))   # PrescribedHydrologyModel defaults, models.jl:73-78
     ti = np.zeros((1, n))
     rho_c_s = call("lho_volumetric_heat_capacity", F64, 0.0, 0.0, sp.rho_c_ds, EARTH)
@@ -246,7 +247,7 @@ def test_heat_analytic():
     t = dt * np.arange(nsteps)
     ts = np.stack([t, t + dt, t + dt / 2], axis=1)
     bcv = np.zeros((nsteps, 3, 2, 2))
-    bcv[:, :, O.FACE_BOTTOM, O.COMP_ENERGY] = A * np.cos(omega * ts)
+    bcv[:, :, M.FACE_BOTTOM, M.COMP_ENERGY] = A * np.cos(omega * ts)
     O.ssprk33(om, dt, nsteps, vl=vl, ti=ti, rhoe=rhoe, bc_stage_values=bcv)
     z, _ = O.grid(0.0, 1.0, n)
     s = math.sqrt(omega / 2) * (1 + 1j)
@@ -272,7 +273,7 @@ def test_coupled_variably_saturated_equilibrium():
     sp, vg = coupled_soil()
     n, dt = 20, 20.0
     nsteps = int(60 * 60 * 24 * 32 / dt)
-    om = O.OracleModel(O.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
+    om = M.CaseModel(M.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
     z, _ = O.grid(-2.0, 0.0, n)
     vl = np.full((1, n), 0.495)
     ti = np.zeros((1, n))
@@ -305,11 +306,11 @@ def test_coupled_variably_saturated_equilibrium():
 def test_richards_variably_saturated_equilibrium():
     """test/SoilModel/richards_equation.jl:1-95: n=50 on (-10,0), 36 days at
     dt=100 s, interface -0.56."""
-    sp = O.default_soil(nu=0.495, S_s=1e-3)
-    vg = O.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
+    sp = M.default_soil(nu=0.495, S_s=1e-3)
+    vg = M.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0)
     n, dt = 50, 100.0
     nsteps = int(60 * 60 * 24 * 36 / dt)
-    om = O.OracleModel(O.MODEL_RICHARDS, n, -10.0, 0.0, soil=sp, vg=vg,
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -10.0, 0.0, soil=sp, vg=vg,
                        bc=zero_flux_bcs(energy=False))
     z, _ = O.grid(-10.0, 0.0, n)
     vl = np.full((1, n), 0.494)
@@ -330,12 +331,12 @@ def test_sand_infiltration_setup_runs():
     bottom.  Its comparison data is downloaded in the reference (:175-185) and is
     not available offline, so only qualitative properties are checked: the front
     moves down, vl stays within [IC, top value], flux leaves through the bottom."""
-    sp = O.default_soil(nu=0.287, S_s=1e-3)
-    vg = O.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075)
+    sp = M.default_soil(nu=0.287, S_s=1e-3)
+    vg = M.default_vg(n=3.96, alpha=2.7, Ksat=34 / 3600 / 100, theta_r=0.075)
     n, dt = 150, 0.25
-    bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.267),
-          (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_FREE_DRAINAGE, 0.0)}
-    om = O.OracleModel(O.MODEL_RICHARDS, n, -1.5, 0.0, soil=sp, vg=vg, bc=bc)
+    bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.267),
+          (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)}
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -1.5, 0.0, soil=sp, vg=vg, bc=bc)
     vl = np.full((1, n), 0.1)
     ti = np.zeros((1, n))
     O.ssprk33(om, dt, 2400, vl=vl, ti=ti)   # 10 minutes of the 48
@@ -349,7 +350,7 @@ def test_sand_infiltration_setup_runs():
 def test_zero_interior_flux_for_hydrostatic_uniform_T():
     sp, vg = coupled_soil()
     n = 40
-    om = O.OracleModel(O.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
+    om = M.CaseModel(M.MODEL_COUPLED, n, -2.0, 0.0, soil=sp, vg=vg, bc=zero_flux_bcs())
     z, _ = O.grid(-2.0, 0.0, n)
     vl = np.array([[call("lho_hydrostatic_profile", F64, vg, zz, -0.7, sp.nu, sp.S_s)
                     for zz in z]])
@@ -370,11 +371,11 @@ def test_invalid_combinations_are_errors():
     vl = np.full((1, n), 0.3)
     ti = np.zeros((1, n))
     # a dynamic component with NoBC has no flux to SetValue -> error
-    om = O.OracleModel(O.MODEL_RICHARDS, n, -1.0, 0.0, soil=sp, vg=vg, bc={})
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -1.0, 0.0, soil=sp, vg=vg, bc={})
     with pytest.raises(ValueError):
         O.rhs(om, vl, ti)
     # zlim[1] < zlim[2] assertion, domain.jl:30
-    om = O.OracleModel(O.MODEL_RICHARDS, n, 0.0, -1.0, soil=sp, vg=vg,
+    om = M.CaseModel(M.MODEL_RICHARDS, n, 0.0, -1.0, soil=sp, vg=vg,
                        bc=zero_flux_bcs(energy=False))
     with pytest.raises(ValueError):
         O.rhs(om, vl, ti)
@@ -383,14 +384,14 @@ def test_invalid_combinations_are_errors():
 def test_bottom_dirichlet_sign_quirk_and_flag():
     """boundary_conditions.jl:395-398: at the bottom the reference flips the whole
     expression, gravity term included.  Default = as written; flag = consistent."""
-    sp = O.default_soil()
-    vg = O.default_vg()
+    sp = M.default_soil()
+    vg = M.default_vg()
     n = 64
-    bc = {(O.FACE_TOP, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.35),
-          (O.FACE_BOTTOM, O.COMP_HYDROLOGY): (O.BC_DIRICHLET, 0.20)}
+    bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.35),
+          (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.20)}
     vl = np.full((1, n), 0.20)
     ti = np.zeros((1, n))
-    om = O.OracleModel(O.MODEL_RICHARDS, n, -1.28, 0.0, soil=sp, vg=vg, bc=bc)
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -1.28, 0.0, soil=sp, vg=vg, bc=bc)
     d_ref = O.rhs(om, vl, ti)["vl"][0]
     om.consistent_bottom_sign = True
     d_fix = O.rhs(om, vl, ti)["vl"][0]
