@@ -13,7 +13,21 @@ min-all-reduced over RCCL inside the timed region.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the driver contract).
+With --gpus N > 1 and no launcher in the environment (no WORLD_SIZE) bench.py starts the N
+ranks itself -- a child `python -m torch.distributed.run` spawned BEFORE this process touches the
+GPU -- relays rank 0's JSON line and fails loudly if fewer than N ranks ran.
+
+Prints ONE JSON line on rank 0 (see the driver contract).  How to read its numbers:
+  value, ms_per_step          the timed loop (K steps between barriers, wall clock, max over ranks)
+  ms_per_step_median/_min     per-step HIP-event durations inside that same loop
+  roofline.frac               bytes the launches really move x K / wall / 8 TB/s  (= the headline rate)
+  roofline.kernel_frac        the dominant kernel alone: bytes moved / its mean HIP-event duration
+                              among the timed steps / 8 TB/s
+  roofline.bytes_per_cell     SURVEY 8(d)'s contract figure (every prognostic read, every tendency
+                              written); bytes_moved_per_cell is smaller when the library knows a
+                              plane is zero (no theta_i read, no d theta_i = 0 store)
+  roofline.traffic            HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC
+                              passes of the SAME command line (profiles/pmc_traffic.json), else null
 
 tests/parity_cases.py supplies the synthetic-input generator (pure numpy) and the C-ABI
 harness (GpuModel); the CPU oracle under oracle/ is loaded and executed in the
@@ -31,7 +45,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy
 
@@ -53,6 +66,12 @@ def parse():
     ap.add_argument("--stepper", action="store_true", default=True,
                     help="also time the device SSPRK33 stepper, both engines (extra JSON fields; default)")
     ap.add_argument("--no-stepper", dest="stepper", action="store_false")
+    ap.add_argument("--no-known-zero", action="store_true",
+                    help="LH_TUNE zero=0: read theta_i and clear the d theta_i plane at every launch "
+                         "(the traffic of SURVEY 8(d)'s byte contract)")
+    ap.add_argument("--no-step-events", action="store_true",
+                    help="no HIP events between the timed steps (kernel statistics then come from a "
+                         "separate back-to-back block)")
     return ap.parse_args()
 
 
@@ -111,6 +130,7 @@ def cpu_baseline(case, seconds):
     path; the reference itself cannot run here) timed on a bounded sample of the
     same workload, all host cores via OpenMP over columns."""
     import dataclasses
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))     # the checker: this leg only
     import oracle_py as O
     import parity_cases as pc
     cores = _usable_cores()
@@ -153,15 +173,71 @@ def cpu_baseline(case, seconds):
                       f"workload, OpenMP over columns on {threads} threads ({el:.1f} s)"}
 
 
+def planes_streamed(case):
+    """(planes read, planes written, NOICE) by one tendency launch of this case: the prognostic
+    planes of the model, minus a theta_i plane the library knows to be zero (kernels without
+    conductivity factors), and never the identically zero d theta_i."""
+    import case_model as M
+    om = case.om
+    factors = bool(om.cf.viscosity_kind or om.cf.impedance_kind)
+    noice = (case.ti is None or not case.ti.any()) and not factors
+    if om.model == M.MODEL_RICHARDS:
+        nr = 1 + (0 if noice else 1) + (1 if om.cf.viscosity_kind else 0)
+        nw = 1
+    elif om.model == M.MODEL_HEAT:
+        nr, nw = 2 + (0 if noice else 1), 1
+    else:
+        nr, nw = 2 + (0 if noice else 1), 2
+    return nr, nw, noice
+
+
+def spawn_ranks(a):
+    """--gpus N without a launcher: start the N ranks as a child torchrun (this process has not
+    touched the GPU and never will), relay rank 0's line, fail if anything is missing."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    other = [ln for ln in r.stdout.splitlines() if not ln.startswith("{")]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        print(f"bench.py: the {a.gpus}-rank child run failed (exit code {r.returncode})", file=sys.stderr)
+        return r.returncode or 1
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != a.gpus:
+        print(f"bench.py: asked for {a.gpus} ranks, the line reports {line.get('n_gpus')}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}: refusing to report a line "
+                         f"for a rank count that is not the one asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {ndev} "
+                         f"(use --backend gloo to rehearse the multi-process path on fewer)")
+    torch.cuda.set_device(local_rank % max(1, ndev))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -169,7 +245,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
 
     import __graft_entry__ as g
     import parity_cases as pc
@@ -186,9 +261,23 @@ def main():
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     gm = pc.GpuModel(case, stream=tstream.cuda_stream)
-    Y, Ya = gm.prognostic_and_aux()
-    dY = gm.state(0)
     L, ctx = gm.L, gm.ctx
+    if a.no_known_zero:
+        F.check(L.lh_set_tuning(ctx, b"zero=0"), ctx)
+    Y, Ya = gm.prognostic_and_aux()     # an all-zero theta_i is a fill: the library knows it is zero
+    dY = gm.state(0)
+    nr, nw, noice = planes_streamed(case)
+    if a.no_known_zero:
+        nr, nw, noice = nr + (1 if noice else 0), nw + (1 if case.om.model != 1 else 0), False
+
+    # The one collective of the path: the min all-reduce of the ranks' stable-step bounds.  Over
+    # RCCL it lives BEHIND the C ABI (lh_comm_init: lh_rhs_stable_dt then delivers the global
+    # minimum, ncclAllReduce on the context's stream); torch.distributed only ships the 128-byte
+    # id, and carries the collective itself only in the gloo rehearsal (ranks sharing one GPU
+    # cannot form an RCCL communicator).
+    native_comm = world > 1 and a.backend == "nccl"
+    if native_comm:
+        pkg.partition.attach_native_comm(ctx, rank, world)
 
     # one-off setup, as a user of the ensemble API gets it on the first rhs! call:
     # the library places the written state in HBM by measurement (lh_tune_placement)
@@ -207,11 +296,12 @@ def main():
     # Every rank does the same work at every N (weak scaling): every third evaluation --
     # once per SSPRK33 step -- is lh_rhs_stable_dt, which also leaves this rank's
     # stable-step bound in device memory from the same pass; for N > 1 that one FT
-    # value is min-all-reduced over RCCL (no host round trip, no second sweep).
+    # value is min-all-reduced (no host round trip, no second sweep).
     def rhs_step(i):
         if i % 3 == 2:
             F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, 0.5, tdt.data_ptr()), ctx)
-            pkg.partition.global_min_dt(tdt)     # no-op for a single rank
+            if not native_comm:
+                pkg.partition.global_min_dt(tdt)     # torch path (gloo rehearsal); no-op for one rank
         else:
             F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
 
@@ -223,12 +313,15 @@ def main():
     for i in range(a.warmup):
         rhs_step(i)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step_events = not a.no_step_events
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if step_events else []
     t0 = time.perf_counter()
-    ev0.record()
     for i in range(a.steps):
+        if step_events:
+            evs[i].record()              # on tstream = the stream the launches go to
         rhs_step(i)
-    ev1.record()
+    if step_events:
+        evs[a.steps].record()
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -236,52 +329,70 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     assert gm.status() == 0, "non-finite tendency during the bench"
+    dt_seen = float(tdt.item()) if a.steps >= 3 or a.warmup >= 3 else None
 
-    # kernel-only average duration at N = 1-style: HIP events on the launch stream
-    # around a back-to-back run of the dominant kernel alone (no collectives)
-    kreps = max(20, min(a.steps, 200))
-    torch.cuda.synchronize()
-    F.check(L.lh_timer_start(ctx), ctx)          # hipEventRecord on the launch stream
-    for _ in range(kreps):
-        F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
-    ms = C.c_float()
-    F.check(L.lh_timer_stop(ctx, C.byref(ms)), ctx)
-    kern_ms = ms.value / kreps
+    # per-step durations inside the timed loop (HIP events on the launch stream)
+    stats = {}
+    if step_events:
+        d = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps)])
+        plain = d[np.arange(a.steps) % 3 != 2]
+        fused = d[np.arange(a.steps) % 3 == 2]
+        stats = {"ms_per_step_median": float(np.median(d)), "ms_per_step_min": float(d.min()),
+                 "ms_per_step_events_mean": float(d.mean())}
+        kern_ms, kern_n = float(plain.mean()), int(plain.size)
+        kern_med, kern_min = float(np.median(plain)), float(plain.min())
+        fused_ms = float(fused.mean()) if fused.size else None
+        kern_src = "per-step HIP events inside the timed loop (the lh_rhs steps)"
+    else:
+        kern_n = max(20, min(a.steps, 200))
+        torch.cuda.synchronize()
+        F.check(L.lh_timer_start(ctx), ctx)
+        for _ in range(kern_n):
+            F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+        ms = C.c_float()
+        F.check(L.lh_timer_stop(ctx, C.byref(ms)), ctx)
+        kern_ms, kern_med, kern_min, fused_ms = ms.value / kern_n, None, None, None
+        kern_src = "HIP events around a separate back-to-back block of lh_rhs launches (after the timed loop)"
 
-    cells = a.ncols * nlev
-    bytes_per_cell = WORKLOADS[a.workload][1]
-    # HBM bytes per launch from the PMC passes of this same command (rocprofv3
-    # cannot run inside the timed process): profiles/pmc_traffic.json, written by
-    # tools/gpu_profile.sh + tools/summarize_prof.py; null when sizes differ
-    traffic = None
+    cells = (hi - lo) * nlev
+    esize = np.dtype(case.dtype).itemsize
+    bytes_per_cell = WORKLOADS[a.workload][1]                       # SURVEY 8(d) contract
+    percol_extra = bytes_per_cell - round(bytes_per_cell / esize) * esize   # C5's per-column block
+    moved_per_cell = (nr + nw) * esize + percol_extra
+    bytes_moved = cells * moved_per_cell
+    ms_per_step = wall / a.steps * 1e3
+    achieved = bytes_moved / (ms_per_step * 1e-3) / 1e9
+    kernel_gbs = bytes_moved / (kern_ms * 1e-3) / 1e9
+
+    # the ceiling of this access pattern on these very planes: the library's no-arithmetic probe
+    # (reads up to nr planes of Y, writes nw planes of dY; it reports its own plane counts)
+    probe = None
+    try:
+        F.check(L.lh_synchronize(ctx), ctx)
+        y_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]      # theta_i last
+        d_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]
+        rp, wp = y_planes[:nr], d_planes[:nw]
+        pm, wm = sum(1 << v for v in rp), sum(1 << v for v in wp)
+        pms = C.c_float()
+        F.check(L.lh_stream_probe(ctx, Y, pm, dY, wm, 20, C.byref(pms)), ctx)
+        probe = {"gbs": cells * esize * (len(rp) + len(wp)) / (pms.value * 1e-3) / 1e9, "ms": pms.value,
+                 "planes_read": len(rp), "planes_written": len(wp)}
+    except Exception as e:      # noqa: BLE001
+        probe = {"error": repr(e)}
+
+    # HBM bytes per launch from committed PMC passes of this same command line (rocprofv3 cannot
+    # run inside the timed process): profiles/pmc_traffic.json, written by tools/gpu_profile.sh
+    traffic, traffic_source, valu_per_cell = None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            tr = json.load(fh).get(a.workload)
-        if tr and tr["ncols"] == a.ncols and tr["nlev"] == nlev:
-            traffic = tr["total_bytes"]
+            tr = json.load(fh).get(a.workload + ("_nozero" if a.no_known_zero else ""))
+        if tr and tr["ncols"] == a.ncols and tr["nlev"] == nlev and tr.get("known_zero", True) != a.no_known_zero:
+            traffic, traffic_source = tr["total_bytes"], tr.get("source")
+            valu_per_cell = tr.get("valu_per_cell")
     except (OSError, ValueError, KeyError):
         pass
-    # the same bytes as one launch moved by a plain device-to-device copy (hipMemcpyAsync through
-    # torch): the "measured copy ceiling" SURVEY 8(d) asks to report beside the spec peak
-    copy_gbs = None
-    try:
-        nb = int(cells * bytes_per_cell / 2)
-        src = torch.empty(nb, dtype=torch.uint8, device="cuda")
-        dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        c1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2 * nb / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9
-        del src, dst
-    except RuntimeError:
-        pass
+
     value = world * cells * a.steps / wall
-    achieved = cells * bytes_per_cell / (kern_ms * 1e-3) / 1e9
     out = {
         "metric": "column-cell updates/sec (RHS evals)",
         "value": value,
@@ -289,7 +400,8 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": wall / a.steps * 1e3,
+        "ms_per_step": ms_per_step,
+        **stats,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -301,14 +413,26 @@ def main():
                    "columns_per_gpu": a.ncols, "levels": nlev,
                    "partition": (f"block over {world} rank(s); " if world > 1 else "single GPU; ") +
                    "every 3rd eval also yields the rank's stable dt (fused)" +
-                   (f"; {'RCCL' if a.backend == 'nccl' else a.backend} min all-reduce of that value"
-                    if world > 1 else "")},
+                   ((f"; min all-reduce of that value: " +
+                     ("RCCL inside the library (lh_comm_init, ncclAllReduce on the launch stream)" if native_comm
+                      else f"torch.distributed {a.backend} (rehearsal on a shared GPU)")) if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kern_ms, "kernel_reps": kreps, "bytes_per_cell": bytes_per_cell,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "frac_is": "bytes_moved_per_launch / ms_per_step / peak (the timed loop, wall clock)",
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "bytes_per_cell": bytes_per_cell, "bytes_moved_per_cell": moved_per_cell,
+                     "planes_read": nr, "planes_written": nw, "theta_i_known_zero": bool(noice),
+                     "bytes_moved_per_launch": bytes_moved,
                      "algorithmic_bytes_per_launch": cells * bytes_per_cell,
-                     "measured_copy_gbs": copy_gbs,
-                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
+                     "kernel_ms": kern_ms, "kernel_ms_median": kern_med, "kernel_ms_min": kern_min,
+                     "kernel_launches_timed": kern_n, "kernel_ms_is": kern_src,
+                     "kernel_achieved": kernel_gbs, "kernel_frac": kernel_gbs / HBM_PEAK_GBS,
+                     "kernel_frac_contract_bytes": cells * bytes_per_cell / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "fused_dt_kernel_ms": fused_ms,
+                     "stream_probe": probe,
+                     "kernel_frac_of_stream_probe": (kernel_gbs / probe["gbs"]) if probe and "gbs" in probe else None,
+                     "valu_per_cell": valu_per_cell},
+        "stable_dt_seen": dt_seen,
         "placement_tuning": placement,
     }
     if a.stepper:
@@ -336,6 +460,8 @@ def main():
             F.check(L.lh_set_tuning(ctx, b""), ctx)
         except Exception as e:      # noqa: BLE001
             out["ssprk33_error"] = repr(e)
+    if native_comm:
+        F.check(L.lh_comm_destroy(ctx), ctx)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(case, a.cpu_seconds)
     gm.close()

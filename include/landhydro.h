@@ -299,6 +299,14 @@ int lh_allreduce_min(lh_ctx*, void* value_device_ft);
  * would have raised DomainError from `^`); synchronises and clears. */
 int lh_get_status(lh_ctx*, uint32_t* flags);
 int lh_synchronize(lh_ctx*);
+/* Streaming ceiling of the column launch on a given set of planes (measurement aid, no
+ * counterpart in the reference): a kernel with rhs_kernel's access pattern and no arithmetic
+ * reads the planes of `in` selected by read_mask and writes the planes of `out` selected by
+ * write_mask (LH_MASK bits), `reps` launches (<= 0: 20); *ms_per_launch = their average
+ * duration by HIP events.  The selected planes of `out` hold unspecified values afterwards.
+ * Synchronises. */
+int lh_stream_probe(lh_ctx*, const lh_state* in, uint32_t read_mask, lh_state* out, uint32_t write_mask,
+                    int reps, float* ms_per_launch);
 /* HIP-event stopwatch on the context's stream */
 int lh_timer_start(lh_ctx*);
 int lh_timer_stop(lh_ctx*, float* elapsed_ms);

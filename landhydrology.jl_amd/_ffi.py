@@ -98,6 +98,7 @@ SIGNATURES = {
     "lh_allreduce_min": (C.c_int, [_P, _P]),
     "lh_get_status": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "lh_synchronize": (C.c_int, [_P]),
+    "lh_stream_probe": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.POINTER(C.c_float)]),
     "lh_timer_start": (C.c_int, [_P]),
     "lh_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }

@@ -44,6 +44,12 @@ struct HostParams {
 struct lh_state {
     lh_ctx* ctx;
     uint32_t mask;
+    // Planes the library KNOWS to be all (+)zeros: set by creation (memset), a zero fill and by
+    // launches that store zeros; cleared by anything else that may write (upload, fill, copy of
+    // a non-zero plane, a launch writing the plane, handing out the device pointer).  A launch
+    // neither reads a theta_i plane known to be zero (rhs_kernel NOICE) nor re-stores the
+    // identically zero d theta_i into a plane that already holds zeros (no kernel stores it).
+    uint32_t zero_mask;
     void* plane[LH_NVARS]; // what kernels address (a slot of a context arena)
 };
 
@@ -261,6 +267,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "persist=")) && sscanf(q + 8, "%d", &v) == 1 && v >= 0 && v <= 2) tu.persist = v;
     if ((q = strstr(t, "graph=")) && sscanf(q + 6, "%d", &v) == 1 && (v == 0 || v == 1)) tu.graph = v;
     if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
+    if ((q = strstr(t, "zero=")) && sscanf(q + 5, "%d", &v) == 1 && (v == 0 || v == 1)) tu.zero = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
@@ -351,9 +358,26 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
         for (int f = 0; f < 2; ++f)
             for (int k = 0; k < 2; ++k) P.bc_value[f][k] = FT(bc_override[f * 2 + k]);
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    const bool tend = mode == 0 || mode == 4;
+    const uint32_t ti_bit = LH_MASK(LH_VAR_THETA_I);
+    // the state theta_i is read from: Ya (HEAT), Y (tendency), the step's base state (fused stages)
+    const lh_state* ti_src = c->cfg.model == LH_MODEL_HEAT ? aux : (tend ? in : base);
+    const bool noice = c->tune.zero != 0 && ti_src && (ti_src->zero_mask & ti_bit);
+    const bool water = model_water(c->cfg.model);
+    // d theta_i = 0 (right_hand_side.jl:182, :359): no kernel stores it -- the tendency state's
+    // theta_i plane is cleared here unless it is known to hold zeros already (normally once per
+    // state; LH_TUNE zero=0 clears it at every launch, the traffic of a kernel that stores it)
+    if (tend && water && (c->tune.zero == 0 || !(out->zero_mask & ti_bit))) {
+        const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+        LH_HIP(c, hipMemsetAsync(out->plane[LH_VAR_THETA_I], 0, bytes, c->stream));
+        out->zero_mask |= ti_bit;
+    }
     launch_rhs<FT>(P, planes_of<FT>(in), planes_of<FT>(aux), planes_of<FT>(base), planes_of<FT>(out),
-                   FT(dt), static_cast<const FT*>(dt_device), mode, factors, any_percol(c), c->math, c->tune, c->stream);
+                   FT(dt), static_cast<const FT*>(dt_device), mode, factors, any_percol(c), noice, c->math, c->tune, c->stream);
     LH_HIP(c, hipGetLastError());
+    // what the launch wrote: vartheta_l / rhoe_int values
+    if (water) out->zero_mask &= ~LH_MASK(LH_VAR_VARTHETA_L);
+    if (model_heat(c->cfg.model)) out->zero_mask &= ~LH_MASK(LH_VAR_RHOE_INT);
     return LH_OK;
 }
 
@@ -410,6 +434,7 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
     if (!s) return fail(c, LH_ENOMEM, "out of host memory");
     s->ctx = c;
     s->mask = mask;
+    s->zero_mask = mask; // every plane is cleared below
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
     for (int i = 0; i < LH_NVARS; ++i) s->plane[i] = nullptr;
     for (int i = 0; i < LH_NVARS; ++i) {
@@ -488,17 +513,20 @@ int run_column_stepper(lh_ctx* c, lh_state* Y, const lh_state* Ya, double dt, co
         }
     }
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    const lh_state* ti_src = c->cfg.model == LH_MODEL_HEAT ? Ya : Y;
+    const bool noice = c->tune.zero != 0 && !factors && ti_src && (ti_src->zero_mask & LH_MASK(LH_VAR_THETA_I));
     if (c->cfg.dtype == LH_F64) {
         DevParams<double> P = make_params<double>(c);
         launch_column_stepper<double>(P, planes_of<double>(Y), planes_of<double>(Ya), dt,
                                       static_cast<const double*>(dt_device), nsteps,
-                                      static_cast<const double*>(d_bcv), factors, any_percol(c), c->stream);
+                                      static_cast<const double*>(d_bcv), factors, any_percol(c), noice, c->stream);
     } else {
         DevParams<float> P = make_params<float>(c);
         launch_column_stepper<float>(P, planes_of<float>(Y), planes_of<float>(Ya), float(dt),
                                      static_cast<const float*>(dt_device), nsteps,
-                                     static_cast<const float*>(d_bcv), factors, any_percol(c), c->stream);
+                                     static_cast<const float*>(d_bcv), factors, any_percol(c), noice, c->stream);
     }
+    Y->zero_mask &= ~(LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_RHOE_INT));
     hipError_t e = hipGetLastError();
     if (d_bcv) { // the launch reads it: wait before releasing
         const hipError_t e2 = hipStreamSynchronize(c->stream);
@@ -908,6 +936,7 @@ static int transfer(lh_ctx* c, lh_state* s, int32_t var, void* host, int64_t ls,
     if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
     if (ls < 1 || cs < 1) return fail(c, LH_EINVAL, "strides must be >= 1");
     (void)hipSetDevice(c->device);
+    if (upload) s->zero_mask &= ~(1u << var);
     const int64_t ncols = c->cfg.ncols;
     const int nlev = c->cfg.nlev;
     const size_t es = c->esize;
@@ -972,6 +1001,8 @@ int lh_state_fill(lh_ctx* c, lh_state* s, int32_t var, double value) {
     if (c->cfg.dtype == LH_F64) launch_fill<double>(static_cast<double*>(s->plane[var]), n, value, c->stream);
     else launch_fill<float>(static_cast<float*>(s->plane[var]), n, float(value), c->stream);
     LH_HIP(c, hipGetLastError());
+    if (value == 0.0 && !std::signbit(value)) s->zero_mask |= 1u << var;
+    else s->zero_mask &= ~(1u << var);
     return LH_OK;
 }
 
@@ -982,8 +1013,10 @@ int lh_state_copy(lh_ctx* c, lh_state* dst, const lh_state* src) {
     (void)hipSetDevice(c->device);
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
     for (int i = 0; i < LH_NVARS; ++i)
-        if (src->mask & (1u << i))
+        if (src->mask & (1u << i)) {
             LH_HIP(c, hipMemcpyAsync(dst->plane[i], src->plane[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+            dst->zero_mask = (dst->zero_mask & ~(1u << i)) | (src->zero_mask & (1u << i));
+        }
     return LH_OK;
 }
 
@@ -991,6 +1024,7 @@ int lh_state_device_ptr(lh_ctx* c, const lh_state* s, int32_t var, void** dptr, 
     if (!c || !s || !dptr) return fail(c, LH_EINVAL, "lh_state_device_ptr: NULL argument");
     if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
     *dptr = s->plane[var];
+    const_cast<lh_state*>(s)->zero_mask &= ~(1u << var); // the caller may write through the pointer
     if (ls) *ls = c->stride;
     if (cs) *cs = 1;
     return LH_OK;
@@ -1052,6 +1086,7 @@ int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* o
         launch_diag<float>(P, planes_of<float>(Y), planes_of<float>(Ya), planes_of<float>(out), any_percol(c), c->math, c->stream);
     }
     LH_HIP(c, hipGetLastError());
+    out->zero_mask = 0;
     return LH_OK;
 }
 
@@ -1335,6 +1370,47 @@ int lh_allreduce_min(lh_ctx* c, void* value_device_ft) {
     if (!c || !value_device_ft) return fail(c, LH_EINVAL, "lh_allreduce_min: NULL argument");
     (void)hipSetDevice(c->device);
     return allreduce_min(c, value_device_ft);
+}
+
+int lh_stream_probe(lh_ctx* c, const lh_state* in, uint32_t read_mask, lh_state* out, uint32_t write_mask,
+                    int reps, float* ms_per_launch) {
+    if (!c || !in || !out || !ms_per_launch) return fail(c, LH_EINVAL, "lh_stream_probe: NULL argument");
+    if (in->ctx != c || out->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if ((in->mask & read_mask) != read_mask || (out->mask & write_mask) != write_mask)
+        return fail(c, LH_ESTATE, "lh_stream_probe: a selected plane does not exist");
+    if (reps < 1) reps = 20;
+    (void)hipSetDevice(c->device);
+    // the selected planes, packed to the front
+    void *rp[4] = {nullptr, nullptr, nullptr, nullptr}, *wp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nr = 0, nw = 0;
+    for (int i = 0; i < LH_NVARS; ++i) {
+        if (read_mask >> i & 1u) rp[nr++] = in->plane[i];
+        if (write_mask >> i & 1u) wp[nw++] = out->plane[i];
+    }
+    const double touched = double(c->cfg.nlev) * double(c->stride) * double(c->esize) * (nr + nw);
+    const bool nt = c->tune.nt >= 0 ? c->tune.nt != 0 : touched > 192.0 * 1024 * 1024; // as launch_rhs_model
+    auto go = [&]() {
+        if (c->cfg.dtype == LH_F64) {
+            Planes<double> pi, po;
+            for (int k = 0; k < 4; ++k) pi.v[k] = static_cast<double*>(rp[k]), po.v[k] = static_cast<double*>(wp[k]);
+            launch_stream_probe<double>(c->cfg.ncols, c->stride, c->cfg.nlev, c->tune.xcd, pi, nr, po, nw, nt, c->stream);
+        } else {
+            Planes<float> pi, po;
+            for (int k = 0; k < 4; ++k) pi.v[k] = static_cast<float*>(rp[k]), po.v[k] = static_cast<float*>(wp[k]);
+            launch_stream_probe<float>(c->cfg.ncols, c->stride, c->cfg.nlev, c->tune.xcd, pi, nr, po, nw, nt, c->stream);
+        }
+    };
+    out->zero_mask &= ~write_mask;
+    for (int r = 0; r < 3; ++r) go();
+    LH_HIP(c, hipGetLastError());
+    LH_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r) go();
+    LH_HIP(c, hipEventRecord(c->ev1, c->stream));
+    LH_HIP(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    LH_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_launch = ms / float(reps);
+    return LH_OK;
 }
 
 int lh_timer_start(lh_ctx* c) {

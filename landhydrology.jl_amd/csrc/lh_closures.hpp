@@ -134,15 +134,18 @@ __device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<
 // WANT_DPSI additionally returns dpsi/dvl for the stable-step bound: with
 // u = S^(-1/m) - 1 = w/t the van Genuchten slope |psi| (u+1)/(n m u Se (nu_eff - theta_r))
 // collapses to |psi| / (n m w (vl_safe - theta_r)); 1/S_s when saturated.
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false>
+// NOICE: the ice plane of the state is known to be all zeros (lh_state zero bits): ti is the
+// literal 0, nu_eff == nu, and the separate psi saturation never exists -- the same numbers as
+// the general path produces for ti == 0, with the ice code compiled out.
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                    FT& psi, FT* dpsi = nullptr) {
-    const FT nu_eff = c.nu - ti;
+    const FT nu_eff = NOICE ? c.nu : c.nu - ti;
     const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps), NaN kept
     const FT num = vls - c.theta_r;
     const FT S = num * c.inv_por;
-    const bool same = (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
+    const bool same = NOICE || (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
 
     // exponents are formed in the exp2 unit of the policy (c.e_* carry the scale)
     if (S < FT(1)) {
@@ -163,7 +166,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             if (WANT_DPSI) *dpsi = c.inv_S_s;
         }
     }
-    if (WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
+    if (!NOICE && WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
         const FT Se = num * mm.rcp(nu_eff - c.theta_r);
         if (Se < FT(1)) {
             const FT ae = mm.log2(Se) * c.e_inv_m;
@@ -190,12 +193,12 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false>
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                FT& psi, FT* dpsi = nullptr) {
     if (M::is_production) {
-        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI>(mm, P, c, vl, ti, T, K, psi, dpsi);
+        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE>(mm, P, c, vl, ti, T, K, psi, dpsi);
     } else {
         water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
         if (WANT_DPSI) { // as the oracle writes it
@@ -220,15 +223,15 @@ __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>&
 // with both kinds of lanes no longer evaluates two pows), and
 // kappa_su^(tl/tw) kappa_sf^(ti/tw) = 2^((tl log2 kappa_su + ti log2 kappa_sf)/tw)
 // is one exp2 instead of two pows.
-template <typename FT, typename M>
+template <typename FT, typename M, bool NOICE = false>
 __device__ __forceinline__ FT kappa_closure_log(const M& mm, const DevParams<FT>& P,
                                                 const ColC<FT>& c, FT vl, FT ti) {
     constexpr FT SC = FT(M::EXP2_SCALE);
-    const FT nu_eff = c.nu - ti;
+    const FT nu_eff = NOICE ? c.nu : c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
-    const FT tw = tl + ti;
+    const FT tw = NOICE ? tl : tl + ti;
     const FT S_r = tw * c.inv_nu;
-    const bool unfrozen = ti < Limits<FT>::eps();
+    const bool unfrozen = NOICE || ti < Limits<FT>::eps();
     // S_r^e: 0 for S_r == 0 (e > 0), NaN for S_r < 0 or NaN (DomainError in the reference).
     // The hardware Float32 log/exp give exactly that (log2 0 = -inf, 2^-inf = 0); the table
     // log2 of the Float64 policy needs a positive normal argument.
@@ -249,7 +252,7 @@ __device__ __forceinline__ FT kappa_closure_log(const M& mm, const DevParams<FT>
         K_e = K_e * ((P.one_minus_om == FT(1)) ? d : mm.pow(d, P.one_minus_om));
     }
     FT k_sat = P.kappa_sat_unfrozen;            // tl/tw == 1 exactly when ti == 0
-    if (ti != FT(0)) {
+    if (!NOICE && ti != FT(0)) {
         const FT itw = mm.rcp(tw);
         k_sat = mm.exp2_scaled(((tl * (P.l2_kappa_sat_unfrozen * SC) + ti * (P.l2_kappa_sat_frozen * SC)) * itw));
     }
@@ -257,10 +260,10 @@ __device__ __forceinline__ FT kappa_closure_log(const M& mm, const DevParams<FT>
     return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
 }
 
-template <typename FT, typename M>
+template <typename FT, typename M, bool NOICE = false>
 __device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
                                             const ColC<FT>& c, FT vl, FT ti) {
-    if constexpr (M::is_production) return kappa_closure_log<FT, M>(mm, P, c, vl, ti);
+    if constexpr (M::is_production) return kappa_closure_log<FT, M, NOICE>(mm, P, c, vl, ti);
     const FT nu_eff = c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
     const FT tw = tl + ti;
@@ -291,14 +294,16 @@ __device__ __forceinline__ FT kappa_closure(const M& mm, const DevParams<FT>& P,
     return K_e * k_sat + (FT(1) - K_e) * c.k_dry;
 }
 
-template <typename FT, typename M>
+template <typename FT, typename M, bool NOICE = false>
 __device__ __forceinline__ FT temperature_closure(const M& mm, const DevParams<FT>& P,
                                                   const ColC<FT>& c, FT vl, FT ti, FT rhoe,
                                                   FT& rho_c_s) {
-    const FT nu_eff = c.nu - ti;
+    const FT nu_eff = NOICE ? c.nu : c.nu - ti;
     const FT tl = liquid_fraction(vl, nu_eff);
-    rho_c_s = P.rho_c_ds + tl * P.rhocp_l + ti * P.rhocp_i;
-    const FT num = rhoe + ti * P.rho_i * P.LH_f0;
+    // (x + 0*y == x bitwise for the finite positive x here; rhoe + 0 == rhoe up to the sign of
+    // a zero, which the division below does not see)
+    rho_c_s = NOICE ? P.rho_c_ds + tl * P.rhocp_l : P.rho_c_ds + tl * P.rhocp_l + ti * P.rhocp_i;
+    const FT num = NOICE ? rhoe : rhoe + ti * P.rho_i * P.LH_f0;
     return P.T_ref + (M::is_production ? num * mm.rcp(rho_c_s) : num / rho_c_s);
 }
 
@@ -307,7 +312,7 @@ __device__ __forceinline__ FT temperature_closure(const M& mm, const DevParams<F
 // methods :295-444.  (vl_c, ti_c, T_c, K_c, psi_c) are the centre values next
 // to the face; K_c/psi_c are the values the interior stage already computed
 // (the reference recomputes them on a 2-element array: same numbers).
-template <typename FT, typename M, int MODEL, bool FACTORS>
+template <typename FT, typename M, int MODEL, bool FACTORS, bool NOICE = false>
 __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>& P,
                                                 const ColC<FT>& c, int face, int64_t col, FT vl_c,
                                                 FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
@@ -333,7 +338,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
         if (ke == BC_FLUX) {
             f_e = ve;
         } else if (ke == BC_DIRICHLET) { // :416-444
-            FT kap_f = kappa_closure<FT, M>(mm, P, c, vl_f, ti_c);
+            FT kap_f = kappa_closure<FT, M, NOICE>(mm, P, c, vl_f, ti_c);
             f_e = sgn * (-kap_f * (T_f - T_c) / dzb);
             if (kappa_face) *kappa_face = kap_f;
         }
@@ -345,7 +350,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
             f_w = -K_c;
         } else if (kh == BC_DIRICHLET) { // :371-401
             FT K_f, psi_f;
-            water_closures<FT, M, FACTORS>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f);
+            water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f);
             if (K_face) *K_face = K_f;
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
                 f_w = K_f * (psi_f - psi_c - dzb) / dzb;

@@ -33,9 +33,10 @@ constexpr bool f32_coupled_vgpr_constants() {
     return sizeof(FT) == 8 || !FACTORS; // Float64 (no occupancy bound there): +2.5 % on f3c64
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false>
 constexpr int rhs_waves_per_simd() {
     if (!M::is_production || FACTORS || PERCOL) return 1;
+    if (MODEL == MODEL_RICHARDS && NOICE) return LH_RHS_WAVES_PER_SIMD; // no ice ring: fits 64 VGPRs in every mode
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
     if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? 7 : 1;
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
@@ -140,7 +141,7 @@ __device__ __forceinline__ bool finite(FT x) {
 // GradientC2F = difference/dz, DivergenceF2C = flux difference/dz with the two
 // boundary faces replaced by the boundary fluxes (SetValue).
 //
-// MODE 0: write the tendency dY.
+// MODE 0: write the tendency dY (its theta_i plane is not touched: d theta_i = 0, see below).
 // MODE 4: MODE 0 plus the local stable-step bound of the same state (the rule of
 //         stable_dt_kernel, from the K, dpsi/dvl, kappa, rho_c_s this pass has in
 //         registers anyway): one integer atomicMin per wave into P.dt_out.
@@ -166,8 +167,13 @@ __device__ __forceinline__ bool finite(FT x) {
 // arithmetic.  The level coordinate z_i comes from LDS (staged once per block):
 // as a global load it would sit in the vector-memory queue behind the next
 // level's prefetch and force a full vmcnt(0) drain every level.
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE>
-__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE>()))
+// NOICE: the theta_i plane the launch would read is known to be all zeros (the zero bits of
+// lh_state): it is not read, ti is the literal 0 and the ice branches are compiled out -- the
+// same numbers the general kernel produces for ti == 0.
+// d theta_i = 0 (right_hand_side.jl:182, :359) is never stored by any mode: the host side keeps
+// the theta_i plane of a tendency state zero (cleared once, tracked by the state's zero bits).
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false>
+__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
@@ -184,10 +190,11 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     FT* s_zc = reinterpret_cast<FT*>(s_dyn);
     const int n = P.nlev;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_zc[i] = P.zc[i];
-    // MODE 4: one LDS word per thread for the wave-level minimum (after the level
-    // coordinates, 16-byte aligned); lanes past the last column leave +inf there
+    // MODE 4: one LDS word per thread for the wave-level maximum of the face diffusivities
+    // (after the level coordinates, 16-byte aligned); lanes past the last column leave the
+    // neutral 0 there
     FT* s_red = reinterpret_cast<FT*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
-    if (WANT_DT) s_red[threadIdx.x] = FT(INFINITY);
+    if (WANT_DT) s_red[threadIdx.x] = FT(0);
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
 
@@ -225,14 +232,13 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
     const int64_t in0 = SEG ? stride * i_first : 0, out0 = SEG ? stride * i_lo : 0;
     const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + in0;
-    const FT* r_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1])) + in0;
+    const FT* r_ti = NOICE ? nullptr : (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1])) + in0;
     const FT* r_re = HEAT ? IN.v[2] + in0 : nullptr;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     const FT* r_Ta = need_Taux ? AUX.v[3] + in0 : nullptr;
     const FT* b_vl = ((MODE == 2 || MODE == 3) && WATER) ? BASE.v[0] + out0 : nullptr;
     const FT* b_re = ((MODE == 2 || MODE == 3) && HEAT) ? BASE.v[2] + out0 : nullptr;
     FT* o_vl = WATER ? OUT.v[0] + out0 : nullptr;
-    FT* o_ti = (WATER && TEND) ? OUT.v[1] + out0 : nullptr;
     FT* o_re = HEAT ? OUT.v[2] + out0 : nullptr;
 
     ColC<FT> c[CPL];
@@ -275,11 +281,11 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     // then moves the pointers one level up
     auto fetch = [&](int slot) {
         rload(r_vl, vl_n[slot]);
-        rload(r_ti, ti_n[slot]);
+        if (!NOICE) rload(r_ti, ti_n[slot]);
         if (HEAT) rload(r_re, re_n[slot]);
         if (need_Taux) rload(r_Ta, Ta_n[slot]);
         r_vl += stride;
-        r_ti += stride;
+        if (!NOICE) r_ti += stride;
         if (HEAT) r_re += stride;
         if (need_Taux) r_Ta += stride;
     };
@@ -307,13 +313,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             }
         }
         if (TEND) {
-            if (WATER) {
-                FT zero[CPL];
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) zero[j] = FT(0);
-                rstore(o_vl, dvl);
-                rstore(o_ti, zero); // d theta_i = 0 (:182, :359)
-            }
+            if (WATER) rstore(o_vl, dvl); // (d theta_i = 0: the plane is kept zero by the host side)
             if (HEAT) rstore(o_re, dre);
         } else {
             auto stage = [&](const FT* brow, FT* orow, const FT (&u)[CPL], const FT (&k)[CPL]) {
@@ -341,7 +341,6 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
         if (WATER) {
             o_vl += stride;
-            if (TEND) o_ti += stride;
             if (MODE == 2 || MODE == 3) b_vl += stride;
         }
         if (HEAT) {
@@ -358,7 +357,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             vl[j] = vl_n[k][j];
-            ti[j] = ti_n[k][j];
+            ti[j] = NOICE ? FT(0) : ti_n[k][j];
             re[j] = re_n[k][j];
             Ta[j] = Ta_n[k][j];
         }
@@ -372,12 +371,12 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             K[j] = psi[j] = h[j] = E[j] = dpsi[j] = FT(0);
             rcs[j] = FT(1);
             if (HEAT) {
-                T[j] = temperature_closure<FT, M>(mm, P, c[j], vl[j], ti[j], re[j], rcs[j]);
-                kap[j] = kappa_closure<FT, M>(mm, P, c[j], vl[j], ti[j]);
+                T[j] = temperature_closure<FT, M, NOICE>(mm, P, c[j], vl[j], ti[j], re[j], rcs[j]);
+                kap[j] = kappa_closure<FT, M, NOICE>(mm, P, c[j], vl[j], ti[j]);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, WANT_DT>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
-                                                              psi[j], &dpsi[j]);
+                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
+                                                                     psi[j], &dpsi[j]);
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
@@ -398,8 +397,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 FT K_f = FT(0), kap_f = FT(0);
-                boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
-                                                       T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f);
+                boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
+                                                              T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f);
                 if (WANT_DT) { // Dirichlet faces: half a cell away, face-state coefficients
                     Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K[j] : FT(0)) * dpsi[j]);
                     if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0)) * mm.rcp(rcs[j]));
@@ -450,8 +449,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             FT K_f = FT(0), kap_f = FT(0);
-            boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
-                                                   K_p[j], psi_p[j], Fe[j], Fw[j], &K_f, &kap_f);
+            boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
+                                                          K_p[j], psi_p[j], Fe[j], Fw[j], &K_f, &kap_f);
             if (WANT_DT) {
                 Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K_p[j] : FT(0)) * dpsi_p[j]);
                 if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap_p[j] : FT(0)) * mm.rcp(rcs_p[j]));
@@ -460,28 +459,32 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         emit(Fw, Fe, vl_p, re_p);
     }
     if (nf_acc != nf_acc) atomicOr(P.status, 1u);
-    if (WANT_DT) { // dt = courant dz^2 / max D over this lane's columns, min over the wave
+    if (WANT_DT) { // dt = courant dz^2 / (max D over the wave's columns), one atomicMin per wave
         using U = typename Bits<FT>::type;
-        FT best = FT(INFINITY);
+        FT dmax = FT(0);
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
-            if ((CPL == 1 || col0 + j < P.ncols) && Dmax[j] > FT(0)) {
-                const FT dtc = (dt * P.dz * P.dz) / Dmax[j];
-                if (dtc < best) best = dtc;
+            if (CPL == 1 || col0 + j < P.ncols) dmax = fmax_ft(dmax, Dmax[j]);
+        // Wave maximum by a binary tree through LDS (x -> fl(c/x) is monotone, so the minimum of
+        // the lanes' quotients IS the quotient of the maximum: one division per wave).  Lanes past
+        // the last column returned early -- a cross-lane shuffle could read their dead registers;
+        // their LDS words hold the neutral 0 from the prologue.  The lanes still here are a prefix
+        // of the wave (col0 grows with the lane), so lane l < off always has its partner's word to
+        // read.  One wave = one 64-word segment; the LDS operations of a wave execute in order, so
+        // the wave barriers only pin the compiler's ordering.
+        FT* seg = s_red + (threadIdx.x & ~63u);
+        const unsigned l = threadIdx.x & 63u;
+        seg[l] = dmax;
+#pragma unroll
+        for (unsigned off = 32; off > 0; off >>= 1) {
+            __builtin_amdgcn_wave_barrier();
+            if (l < off) {
+                dmax = fmax_ft(dmax, seg[l + off]);
+                seg[l] = dmax;
             }
-        // Wave minimum through LDS: lanes past the last column returned early, so a
-        // cross-lane shuffle could read their dead registers; their LDS words hold
-        // +inf from the prologue.  One wave = one 64-word segment, no block barrier.
-        s_red[threadIdx.x] = best;
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long active = __ballot(1);
-        const int first = __ffsll((long long)active) - 1;
-        if ((int)(threadIdx.x & 63) == first) {
-            const FT* seg = s_red + (threadIdx.x & ~63u);
-#pragma unroll 8
-            for (int l = 0; l < 64; ++l) best = fmin_ft(best, seg[l]);
         }
-        if ((int)(threadIdx.x & 63) == first && best < FT(INFINITY)) {
+        if (l == 0 && dmax > FT(0)) {
+            const FT best = (dt * P.dz * P.dz) / dmax;
             U b;
             __builtin_memcpy(&b, &best, sizeof(FT));
             atomicMin(reinterpret_cast<U*>(P.dt_out), b);
@@ -504,7 +507,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 // WAVE: a column is one wavefront (nlev <= 64).  The neighbour exchange then needs no
 // workgroup barrier -- LDS operations of one wave execute in order -- so a workgroup can hold
 // many columns (wide contiguous pieces for the plane tiles) without coupling their arithmetic.
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE, bool NOICE = false>
 __global__ void __launch_bounds__(1024)
 column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
                       const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
@@ -557,12 +560,12 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     auto fetched = [&](int k) -> FT { return (col_raw < P.ncols) ? tiles[k * tile_n + slot * n + ic] : FT(0); };
     // HEAT reads the prescribed water fields from Ya (right_hand_side.jl:200-201)
     request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
-    request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
+    if (!NOICE) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
     if (HEAT) request(Y.v[2], 2);
     if (need_Taux) request(AUX.v[3], 3);
     __syncthreads();
     FT y_vl = fetched(0);
-    const FT ti = fetched(1);
+    const FT ti = NOICE ? FT(0) : fetched(1); // NOICE: the theta_i plane is known to be all zeros
     FT y_re = HEAT ? fetched(2) : FT(0);
     const FT Ta = need_Taux ? fetched(3) : FT(288);
     __syncthreads();
@@ -581,11 +584,11 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             }
             FT T = Ta, kap = FT(0), K = FT(0), psi = FT(0), h = FT(0), E = FT(0), rcs = FT(1);
             if (HEAT) {
-                T = temperature_closure<FT, M>(mm, P, c, u_vl, ti, u_re, rcs);
-                kap = kappa_closure<FT, M>(mm, P, c, u_vl, ti);
+                T = temperature_closure<FT, M, NOICE>(mm, P, c, u_vl, ti, u_re, rcs);
+                kap = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl, ti);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, false>(mm, P, c, u_vl, ti, T, K, psi);
+                water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, u_vl, ti, T, K, psi);
                 h = psi + z;
                 if (HEAT) E = (P.rhocp_l * (T - P.T_ref)) * K; // rho_e_int_l * K (:364)
             }
@@ -602,8 +605,8 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             FT Fw_b = FT(0), Fe_b = FT(0);
             const bool at_bottom = (i == 0), at_top = (i == n - 1);
             if (i < n && (at_bottom || at_top))
-                boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, u_vl, ti,
-                                                       T, K, psi, Fe_b, Fw_b);
+                boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, u_vl, ti,
+                                                              T, K, psi, Fe_b, Fw_b);
             if (i < n) {
                 if (at_bottom) {
                     Fw_lo = Fw_b;
@@ -622,7 +625,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 }
                 if (at_top) {
                     if (at_bottom) // a one-cell column: the same thread owns both faces
-                        boundary_fluxes<FT, M, MODEL, FACTORS>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
+                        boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
                     else {
                         Fw_hi = Fw_b;
                         Fe_hi = Fe_b;
@@ -849,6 +852,70 @@ strided_copy_kernel(FT* plane, int64_t stride, FT* user, int64_t ls, int64_t cs,
     }
 }
 
+// ------------------------------------------------------- streaming probe
+// The access pattern of rhs_kernel with the arithmetic taken out: one lane per CPL columns
+// marches bottom -> top, reads one row of each of NR planes per level (PF levels in flight),
+// and stores their sum into each of NW planes -- same buffer-descriptor row access, same
+// nontemporal policy, same workgroup -> column-block map.  Its rate is the ceiling the column
+// launch can reach on THIS set of planes (lh_stream_probe).
+template <typename FT, int CPL, int PF, bool NT>
+__global__ void __launch_bounds__(256, 8)
+stream_probe_kernel(const int64_t ncols, const int64_t stride, const int nlev, const int xcd_remap,
+                    const Planes<FT> IN, const int nr, const Planes<FT> OUT, const int nw) {
+    static_assert(sizeof(FT) * CPL == 8, "one 8-byte access per lane");
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const int64_t col0 = (int64_t(blk) * blockDim.x + threadIdx.x) * CPL;
+    if (col0 >= ncols) return;
+    const unsigned lane_byte = (unsigned)col0 * (unsigned)sizeof(FT);
+    const unsigned row_bytes = (unsigned)(stride * (int64_t)sizeof(FT));
+    const FT* r[4];
+    FT* w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[k] = IN.v[k];
+        w[k] = OUT.v[k];
+    }
+    FT ring[PF][4][CPL];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) ring[q][k][j] = FT(0);
+    auto fetch = [&](int slot) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nr) {
+                bload<FT, CPL, NT>(r[k], row_bytes, lane_byte, ring[slot][k]);
+                r[k] += stride;
+            }
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+        if (q < nlev) fetch(q);
+    for (int i0 = 0; i0 < nlev; i0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int i = i0 + q;
+            if (PF > 1 && i >= nlev) break;
+            FT x[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) x[j] = (ring[q][0][j] + ring[q][1][j]) + (ring[q][2][j] + ring[q][3][j]);
+            if (i + PF < nlev) fetch(q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nw) {
+                    bstore<FT, CPL, NT>(w[k], row_bytes, lane_byte, x);
+                    w[k] += stride;
+                }
+        }
+    }
+}
+
 template <typename FT>
 __global__ void __launch_bounds__(256) fill_kernel(FT* p, int64_t n, FT v) {
     int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -874,7 +941,7 @@ static inline dim3 grid_for(int64_t work, int block) {
     return dim3((unsigned)((work + block - 1) / block));
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, bool NOICE>
 static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                             const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
                             int mode, int block, hipStream_t s) {
@@ -884,26 +951,26 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
     // dynamic LDS: z_i, plus one word per thread for the mode-4 reduction
     const unsigned dyn = (unsigned)((((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15) +
                                     (mode == 4 ? (size_t)block * sizeof(FT) : 0));
-    if (!M::is_production) { // MathLibm: tendency only
-        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
-        return;
-    }
-    switch (mode) {
-        case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-        case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-        case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-        case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-        default: // 4: tendency + stable-step bound; the minimum starts at +inf
-            hipLaunchKernelGGL((init_bits_kernel<FT>), dim3(1), dim3(1), 0, s, reinterpret_cast<typename Bits<FT>::type*>(P.dt_out));
-            hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
-            break;
+    if constexpr (!M::is_production) { // MathLibm: tendency only (the other modes are never instantiated)
+        hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, false>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
+    } else {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            default: // 4: tendency + stable-step bound; the minimum starts at +inf
+                hipLaunchKernelGGL((init_bits_kernel<FT>), dim3(1), dim3(1), 0, s, reinterpret_cast<typename Bits<FT>::type*>(P.dt_out));
+                hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
+                break;
+        }
     }
 }
 
 template <typename FT, int MODEL, typename M>
 static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                              const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
-                             int mode, bool factors, bool percol, const Tune& tune, hipStream_t s) {
+                             int mode, bool factors, bool percol, bool noice, const Tune& tune, hipStream_t s) {
     using CFG = typename DefaultCfg<FT>::type;
     const int block = tune.block > 0 ? tune.block : 256;
 #ifdef LH_TUNING_VARIANTS
@@ -913,7 +980,7 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
         const int cplv = tune.cpl > 0 ? tune.cpl : CFG::CPL, pfv = tune.pf > 0 ? tune.pf : CFG::PF;
 #define LH_TRY(C, F, N)                                                                            \
     if (cplv == C && pfv == F && ntv == N) {                                                       \
-        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
+        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M, false>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
         return;                                                                                    \
     }
         LH_TRY(1, 1, true) LH_TRY(1, 2, true) LH_TRY(1, 3, true) LH_TRY(1, 4, true)
@@ -931,20 +998,25 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     using CFGP = KCfg<CFG::CPL, CFG::PF, false>;
     using CFGS = KCfg<CFG::CPL, CFG::PF, false, true>; // level-segmented (small ensembles: cache-resident)
     const bool seg = M::is_production && P.seg_len > 0 && P.seg_len < P.nlev;
-#define LH_GO(F, PC)                                                                                  \
+    // the no-ice kernels exist for the production math without conductivity factors
+    const bool ni = noice && M::is_production && !factors;
+#define LH_GO3(F, PC, NI)                                                                             \
     do {                                                                                              \
-        if (seg) launch_rhs_mode<FT, MODEL, F, PC, CFGS, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
-        else if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
-        else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M>(P, in, aux, base, out, dt, dt_dev, mode, block, s);   \
+        if (seg) launch_rhs_mode<FT, MODEL, F, PC, CFGS, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+        else if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+        else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s);   \
     } while (0)
     if (factors) {
-        if (percol) LH_GO(true, true);
-        else LH_GO(true, false);
+        if (percol) LH_GO3(true, true, false);
+        else LH_GO3(true, false, false);
+    } else if (ni) {
+        if (percol) LH_GO3(false, true, true);
+        else LH_GO3(false, false, true);
     } else {
-        if (percol) LH_GO(false, true);
-        else LH_GO(false, false);
+        if (percol) LH_GO3(false, true, false);
+        else LH_GO3(false, false, false);
     }
-#undef LH_GO
+#undef LH_GO3
 }
 
 // All rhs_kernel variants of one model.  Each (FT, MODEL) pair is instantiated in its own
@@ -952,20 +1024,20 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
 template <typename FT, int MODEL>
 void launch_rhs_for_model(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                           const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
-                          int mode, bool factors, bool percol, int math, const Tune& tune,
+                          int mode, bool factors, bool percol, bool noice, int math, const Tune& tune,
                           hipStream_t s) {
     // MathLibm is a parity-debugging policy for the tendency itself (mode 0);
     // the fused SSPRK33 stages and mode 4 always run the production math.
     if (math == MATH_LIBM && mode == 0)
-        launch_rhs_model<FT, MODEL, MathLibm<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s);
+        launch_rhs_model<FT, MODEL, MathLibm<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, false, tune, s);
     else
-        launch_rhs_model<FT, MODEL, MathFast<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, tune, s);
+        launch_rhs_model<FT, MODEL, MathFast<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, noice, tune, s);
 }
 
 template <typename FT, int MODEL>
 void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux,
                                      FT dt, const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors,
-                                     bool percol, hipStream_t s) {
+                                     bool percol, bool noice, hipStream_t s) {
     const unsigned tpc = (unsigned)((P.nlev + 63) / 64 * 64);
     // columns per workgroup
     // columns per workgroup: 256 threads when the stages need workgroup barriers; 8 one-wave
@@ -977,26 +1049,29 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
     const unsigned dyn = (unsigned)(cpb * 5 * (size_t)P.nlev * sizeof(FT));
     using M = MathFast<FT>;
-#define LH_CS(F, PC)                                                                                              \
+#define LH_CS(F, PC, NI)                                                                                          \
     do {                                                                                                          \
-        if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);  \
-        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
+        if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);  \
+        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
     } while (0)
     if (factors) {
-        if (percol) LH_CS(true, true);
-        else LH_CS(true, false);
+        if (percol) LH_CS(true, true, false);
+        else LH_CS(true, false, false);
+    } else if (noice) {
+        if (percol) LH_CS(false, true, true);
+        else LH_CS(false, false, true);
     } else {
-        if (percol) LH_CS(false, true);
-        else LH_CS(false, false);
+        if (percol) LH_CS(false, true, false);
+        else LH_CS(false, false, false);
     }
 #undef LH_CS
 }
 
 #define LH_CS_MODEL_ARGS(FT) \
-    const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, FT, const FT*, int64_t, const FT*, bool, bool, hipStream_t
+    const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, FT, const FT*, int64_t, const FT*, bool, bool, bool, hipStream_t
 #define LH_RHS_MODEL_ARGS(FT)                                                                        \
     const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, const Planes<FT>&, \
-        FT, const FT*, int, bool, bool, int, const Tune&, hipStream_t
+        FT, const FT*, int, bool, bool, bool, int, const Tune&, hipStream_t
 #ifndef LH_TU_MODEL // the common translation unit only dispatches
 extern template void launch_rhs_for_model<double, MODEL_RICHARDS>(LH_RHS_MODEL_ARGS(double));
 extern template void launch_rhs_for_model<double, MODEL_HEAT>(LH_RHS_MODEL_ARGS(double));
@@ -1018,22 +1093,22 @@ extern template void launch_column_stepper_for_model<float, MODEL_COUPLED>(LH_CS
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
-                bool factors, bool percol, int math, const Tune& tune, hipStream_t s) {
+                bool factors, bool percol, bool noice, int math, const Tune& tune, hipStream_t s) {
     switch (P.model) {
-        case MODEL_RICHARDS: launch_rhs_for_model<FT, MODEL_RICHARDS>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
-        case MODEL_HEAT: launch_rhs_for_model<FT, MODEL_HEAT>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
-        default: launch_rhs_for_model<FT, MODEL_COUPLED>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, math, tune, s); break;
+        case MODEL_RICHARDS: launch_rhs_for_model<FT, MODEL_RICHARDS>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, noice, math, tune, s); break;
+        case MODEL_HEAT: launch_rhs_for_model<FT, MODEL_HEAT>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, noice, math, tune, s); break;
+        default: launch_rhs_for_model<FT, MODEL_COUPLED>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, noice, math, tune, s); break;
     }
 }
 
 template <typename FT>
 void launch_column_stepper(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux, FT dt,
                            const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors, bool percol,
-                           hipStream_t s) {
+                           bool noice, hipStream_t s) {
     switch (P.model) {
-        case MODEL_RICHARDS: launch_column_stepper_for_model<FT, MODEL_RICHARDS>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
-        case MODEL_HEAT: launch_column_stepper_for_model<FT, MODEL_HEAT>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
-        default: launch_column_stepper_for_model<FT, MODEL_COUPLED>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, s); break;
+        case MODEL_RICHARDS: launch_column_stepper_for_model<FT, MODEL_RICHARDS>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, noice, s); break;
+        case MODEL_HEAT: launch_column_stepper_for_model<FT, MODEL_HEAT>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, noice, s); break;
+        default: launch_column_stepper_for_model<FT, MODEL_COUPLED>(P, Y, aux, dt, dt_dev, nsteps, bcv, factors, percol, noice, s); break;
     }
 }
 
@@ -1092,6 +1167,17 @@ void launch_strided_copy(FT* plane, int64_t stride, FT* user, int64_t ls, int64_
 }
 
 template <typename FT>
+void launch_stream_probe(int64_t ncols, int64_t stride, int nlev, int xcd_remap, const Planes<FT>& in, int nr,
+                         const Planes<FT>& out, int nw, bool nt, hipStream_t s) {
+    using CFG = typename DefaultCfg<FT>::type;
+    constexpr int CPL = CFG::CPL, PF = CFG::PF;
+    const int64_t lanes = (ncols + CPL - 1) / CPL;
+    dim3 g = grid_for(lanes, 256), b(256);
+    if (nt) hipLaunchKernelGGL((stream_probe_kernel<FT, CPL, PF, true>), g, b, 0, s, ncols, stride, nlev, xcd_remap, in, nr, out, nw);
+    else hipLaunchKernelGGL((stream_probe_kernel<FT, CPL, PF, false>), g, b, 0, s, ncols, stride, nlev, xcd_remap, in, nr, out, nw);
+}
+
+template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -1108,15 +1194,17 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
 #define LH_INSTANTIATE(FT)                                                                            \
     template void launch_rhs<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,          \
                                  const Planes<FT>&, const Planes<FT>&, FT, const FT*, int, bool, bool, \
-                                 int, const Tune&, hipStream_t);                                                      \
+                                 bool, int, const Tune&, hipStream_t);                                                      \
     template void launch_column_stepper<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, \
-                                            FT, const FT*, int64_t, const FT*, bool, bool, hipStream_t); \
+                                            FT, const FT*, int64_t, const FT*, bool, bool, bool, hipStream_t); \
     template void launch_diag<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,         \
                                   const Planes<FT>&, bool, int, hipStream_t);                         \
     template void launch_stable_dt<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,    \
                                        FT, void*, bool, hipStream_t);                                 \
     template void launch_strided_copy<FT>(FT*, int64_t, FT*, int64_t, int64_t, int64_t, int, bool,    \
                                           hipStream_t);                                               \
+    template void launch_stream_probe<FT>(int64_t, int64_t, int, int, const Planes<FT>&, int,         \
+                                          const Planes<FT>&, int, bool, hipStream_t);                 \
     template void launch_fill<FT>(FT*, int64_t, FT, hipStream_t);                                     \
     template void launch_convert<FT>(FT*, const double*, int64_t, hipStream_t);
 

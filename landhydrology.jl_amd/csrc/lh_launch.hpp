@@ -24,18 +24,19 @@ struct Tune {
     int persist = 1; // persistent column stepper (0: fused-stage launches instead)
     int graph = 1;   // replay blocks of fused SSPRK33 steps of small ensembles as a hipGraph (0: plain launches)
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
+    int zero = 1;    // use the states' known-zero plane bits (0: always read theta_i and store d theta_i = 0)
 };
 
 // mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
-                bool factors, bool percol, int math, const Tune& tune, hipStream_t s);
+                bool factors, bool percol, bool noice, int math, const Tune& tune, hipStream_t s);
 // nsteps fused SSPRK33 steps of a small ensemble in ONE launch (workgroup = column, thread = cell)
 template <typename FT>
 void launch_column_stepper(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux, FT dt,
                            const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors, bool percol,
-                           hipStream_t s);
+                           bool noice, hipStream_t s);
 template <typename FT>
 void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                  const Planes<FT>& out, bool percol, int math, hipStream_t s);
@@ -45,6 +46,10 @@ void launch_stable_dt(const DevParams<FT>& P, const Planes<FT>& in, const Planes
 template <typename FT>
 void launch_strided_copy(FT* plane, int64_t stride, FT* user, int64_t ls, int64_t cs,
                          int64_t ncols, int nlev, bool to_plane, hipStream_t s);
+// the column launch's access pattern without arithmetic: nr planes of `in` read, nw planes of `out` written
+template <typename FT>
+void launch_stream_probe(int64_t ncols, int64_t stride, int nlev, int xcd_remap, const Planes<FT>& in, int nr,
+                         const Planes<FT>& out, int nw, bool nt, hipStream_t s);
 template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s);
 template <typename FT>

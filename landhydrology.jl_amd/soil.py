@@ -345,9 +345,11 @@ class FieldVector:
     def set(self, name, value):
         d = self.model.domain
         a = np.asarray(value, dtype=d.FT)
-        if a.ndim == 0:
-            F.check(F.lib().lh_state_fill(self._be.ctx, self.handle, _VAR[name], float(a)),
-                    self._be.ctx)
+        if a.ndim == 0 or not a.any():
+            # a constant (or all-zero) field is a fill; the library then knows a zero plane is
+            # zero: a launch neither reads a zero θ_i plane nor re-stores dθ_i = 0
+            F.check(F.lib().lh_state_fill(self._be.ctx, self.handle, _VAR[name],
+                                          float(a) if a.ndim == 0 else 0.0), self._be.ctx)
             return
         if a.ndim == 1:
             a = np.broadcast_to(a, (d.ncolumns, d.nelements))

@@ -353,6 +353,11 @@ class GpuModel:
     def upload(self, h, var, a):
         a = np.asarray(a)
         assert a.dtype == self.case.dtype and a.ndim == 2
+        if not a.any():
+            # an all-zero field is a fill: the library then KNOWS the plane is zero and neither
+            # reads a zero theta_i plane nor re-stores d theta_i = 0 (the host mirror does the same)
+            self.F.check(self.L.lh_state_fill(self.ctx, h, var, 0.0), self.ctx)
+            return
         ls, cs = self._strides(a)
         self.F.check(self.L.lh_upload(self.ctx, h, var, a.ctypes.data, ls, cs), self.ctx)
 

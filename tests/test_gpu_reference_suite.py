@@ -55,7 +55,7 @@ def test_default_ic_and_single_rhs(lh):
     assert np.allclose(dY.soil.θ_i[0], 0.0, atol=0)                          # :221
     assert np.allclose(dY.soil.ρe_int[0], 0.0, atol=1e-12)                   # :222
     S = pc.O.fn("lho_effective_saturation", FT)(0.5, 0.25, 0.0)
-    K = pc.O.fn("lho_hydraulic_conductivity", FT)(pc.coupled_soil()[1], S, 1.0, 1.0)
+    K = pc.O.fn("lho_hydraulic_conductivity", FT)(pc.O.as_c(pc.coupled_soil()[1]), S, 1.0, 1.0)
     flux = np.zeros(21) - K
     flux[0] = flux[-1] = 0.0
     minus_div = -(flux[1:] - flux[:-1]) / 0.1

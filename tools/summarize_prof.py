@@ -44,11 +44,11 @@ for f in glob.glob(os.path.join(d, "bench_trace.log")):
             bench_line = json.loads(line)
 # The run starts with the placement trials of lh_tune_placement (the same kernel on other
 # plane slots, some of them slow) and ends with the back-to-back block bench.py times with
-# HIP events (roofline.kernel_ms over roofline.kernel_reps launches): compare like with like.
+# HIP events (roofline.kernel_ms over roofline.kernel_launches_timed launches): compare like with like.
 disp = [r for r in rows("trace/**/*kernel_trace.csv") if r.get("Kernel_Name") == dom]
 if disp and bench_line:
     disp.sort(key=lambda r: int(r["Start_Timestamp"]))
-    n = int(bench_line["roofline"].get("kernel_reps", 0)) or len(disp)
+    n = int(bench_line["roofline"].get("kernel_launches_timed", 0) or bench_line["roofline"].get("kernel_reps", 0)) or len(disp)
     last = disp[-n:]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
     print(f"== dominant kernel, last {len(last)} dispatches (the HIP-event timed block of bench.py): "
@@ -57,4 +57,15 @@ if disp and bench_line:
     print(f"   all {len(alld)} dispatches incl. placement trials and warm-up: avg_ns={sum(alld) / len(alld):.0f}")
 if bench_line:
     print("== bench line (profiled run):", json.dumps({k: bench_line.get(k) for k in
-                                                        ("value", "ms_per_step", "roofline", "placement_tuning")}))
+                                                        ("value", "ms_per_step", "ms_per_step_median", "ms_per_step_min",
+                                                         "roofline", "placement_tuning")}))
+# machine-readable record for profiles/pmc_traffic.json
+if bench_line and dom:
+    rec = {"kernel": dom[:160]}
+    for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", "SQ_INSTS_VALU"),
+                     ("pmc_sq", "SQ_INSTS_SALU"), ("pmc_sq", "SQ_WAVES")):
+        v = [float(r["Counter_Value"]) for r in rows(f"{sub}/**/*counter_collection.csv")
+             if r.get("Kernel_Name") == dom and r["Counter_Name"] == key]
+        if v:
+            rec[key] = sum(v) / len(v)
+    print("== record:", json.dumps(rec))
