@@ -173,6 +173,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.model = c->cfg.model;
     P.dz = (FT(c->cfg.zmax) - FT(c->cfg.zmin)) / FT(c->cfg.nlev);
     P.inv_dz = FT(1) / P.dz;
+    P.half_inv_dz = FT(0.5) * P.inv_dz;
     P.half_dz = P.dz / FT(2);
     P.zc = static_cast<const FT*>(c->d_zc);
     P.vg_n = FT(h.vg.n);
@@ -227,7 +228,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_nu = FT(1) / u.nu;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
     {   // exponent multipliers in the exp2 unit of the production math (lh_fastmath.hpp)
-        const FT sc = sizeof(FT) == 8 ? FT(128) : FT(1);
+        const FT sc = sizeof(FT) == 8 ? FT(MathFast<double>::EXP2_SCALE) : FT(1);
         u.e_one = sc;
         u.e_inv_m = sc * u.inv_m;
         u.e_m = sc * u.m;
@@ -269,7 +270,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
     if ((q = strstr(t, "zero=")) && sscanf(q + 5, "%d", &v) == 1 && (v == 0 || v == 1)) tu.zero = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
-    if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 256 && v % 64 == 0) tu.block = v;
+    if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 1024 && v % 64 == 0) tu.block = v;
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
     if ((q = strstr(t, "nt=")) && sscanf(q + 3, "%d", &v) == 1) tu.nt = v;

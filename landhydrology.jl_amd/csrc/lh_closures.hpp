@@ -142,7 +142,9 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                    FT& psi, FT* dpsi = nullptr) {
     const FT nu_eff = NOICE ? c.nu : c.nu - ti;
-    const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim; // max(vl, theta_r + eps), NaN kept
+    // max(vl, theta_r + eps), NaN kept (a compare and two 32-bit selects; v_max + a NaN put back
+    // by 0 * vl costs the same once the canonicalising v_max or the asm hazard nop is counted)
+    const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
     const FT num = vls - c.theta_r;
     const FT S = num * c.inv_por;
     const bool same = NOICE || (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
@@ -160,9 +162,13 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             if (WANT_DPSI) *dpsi = -psi * mm.rcp(c.n * c.m * w * num);
         }
     } else {
+        // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
+        // compiler evaluates it for every cell and selects, six VALU instructions per cell)
         K = c.Ksat; // K_r = 1
         if (WANT_PSI && same) {
-            psi = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            FT ps = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            asm volatile("" : "+v"(ps));
+            psi = ps;
             if (WANT_DPSI) *dpsi = c.inv_S_s;
         }
     }

@@ -39,6 +39,7 @@ struct DevParams {
     int32_t model;
     FT dz;        // (zmax - zmin) / nlev            (domain.jl:64)
     FT inv_dz;    // 1 / dz
+    FT half_inv_dz; // (1/2) / dz: the arithmetic-mean factor of InterpolateC2F folded into GradientC2F (exact)
     FT half_dz;   // boundary centre-to-face distance (boundary_conditions.jl:196-208)
     const FT* zc; // device array [nlev], coordinates(cs)
 

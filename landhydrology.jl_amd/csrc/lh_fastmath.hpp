@@ -4,14 +4,18 @@
 //                parity debugging (LH_MATH_LIBM) and once-per-column constants.
 //  MathFast<FT>  the production policy.
 //     double: pow(x, y) = exp2(y * log2 x) with LDS-resident tables --
-//        log2: x = m 2^e (v_frexp), 256 intervals on m in [0.5, 1) give
-//              (1/c, log2 c) from LDS, r = fma(m, 1/c, -1) with |r| < 2^-8 and a
-//              degree-6 polynomial; c = 0.5 and c = 1 at the two ends so
-//              log2(1) == 0 exactly and arguments next to 1 lose nothing;
-//        exp2: t = k/128 + r, 2^(j/128) from LDS, degree-5 polynomial, v_ldexp.
-//        ~37 VALU instructions per pow against several hundred for ocml's
-//        correctly-rounded pow: CDNA4 has no f64 transcendental unit, and at
-//        1e6 x 64 cells the f64 pows -- not HBM -- set the kernel's speed.
+//        log2: x = m 2^e (v_frexp), 2048 intervals on m in [0.5, 1) give
+//              (1/c, log2 c) from LDS, r = fma(m, 1/c, -1) with |r| <= 2^-12 and a
+//              degree-4 polynomial; c = 0.5 and c = 1 at the two ends so
+//              log2(1) == 0 exactly and arguments next to 1 keep their relative accuracy
+//              (3 ulp there, where log2 itself amplifies the argument's rounding 4096-fold);
+//        exp2: t = k/2048 + r, 2^(j/2048) from LDS, degree-3 polynomial, v_ldexp.
+//        11 VALU instructions per log2 or exp2 against several hundred for ocml's
+//        correctly-rounded pow: CDNA4 has no f64 transcendental unit, and once the
+//        launch streams only the planes it must (known-zero planes) the f64 closures --
+//        not HBM -- set the kernel's speed: every polynomial term is launch time.  The
+//        tables take 48 KiB of LDS per workgroup, so the Float64 kernels run 1024- or
+//        512-thread workgroups (2 or 3 per CU).
 //        Error: |rel| <= (2.5 |y log2 x| ln 2 + 2) 2^-53, i.e. the rounding of
 //        the exponent product; the parity tolerance model accounts for it.
 //     float: v_log_f32 / v_exp_f32 (hardware, ~1 ulp each).
@@ -29,11 +33,13 @@ template <> struct Limits<float> {
 };
 
 // ---------------------------------------------------------------- tables
-constexpr int LOG_TAB_N = 256;  // entries of (1/c, log2 c)
-constexpr int EXP_TAB_N = 128;  // entries of 2^(j/128)
+constexpr int LOG_TAB_N = 2048; // entries of (1/c, log2 c)
+constexpr int LOG_TAB_BITS = 11;
+constexpr int EXP_TAB_N = 2048; // entries of 2^(j/2048)
+constexpr int EXP_TAB_BITS = 11;
 constexpr int MATH_TAB_DOUBLES = 2 * LOG_TAB_N + EXP_TAB_N;
 
-// Shared-memory image of the tables: [0, 512) log pairs, [512, 640) exp2.
+// Shared-memory image of the tables: [0, 2 LOG_TAB_N) log pairs, then EXP_TAB_N exp2 values.
 struct MathTables {
     const double* log_tab; // LDS, pairs
     const double* exp_tab; // LDS
@@ -90,16 +96,16 @@ __device__ __forceinline__ double vgpr_resident(double k) {
 template <> struct MathFast<double> {
     static constexpr bool uses_tables = true;
     static constexpr bool is_production = true;
-    // exponents are handed to exp2 in units of 1/128 (x128): the argument reduction
-    // is then three additions, with no multiply by 128 and no v_mov/v_fmac pairs
-    static constexpr double EXP2_SCALE = 128.0;
+    // exponents are handed to exp2 in units of 1/2048 (x2048): the argument reduction
+    // is then three additions, with no multiply by 2048 and no v_mov/v_fmac pairs
+    static constexpr double EXP2_SCALE = double(EXP_TAB_N);
     MathTables tb;
-    // second-highest polynomial coefficients and the rounding shifter, VGPR-resident:
-    // the first Horner step needs two constants and only one may come from SGPRs
-    double c5v, q4v, shiftv;
+    // the polynomial coefficients the first Horner steps need next to a second constant, and the
+    // rounding shifter, VGPR-resident: only one operand of a VOP3 may come from SGPRs/literals
+    double c3v, q2v, shiftv;
     __device__ __forceinline__ explicit MathFast(const MathTables& t)
-        : tb(t), c5v(vgpr_resident(0.28853900817779268)),
-          q4v(vgpr_resident(9.6181291076284772e-3 / (128.0 * 128.0 * 128.0 * 128.0))),
+        : tb(t), c3v(vgpr_resident(0.48089834696298783)),
+          q2v(vgpr_resident(5.727446255423176e-08)),
           shiftv(vgpr_resident(6755399441055744.0)) {}
 
     // log2 of a positive, finite, normal x
@@ -107,41 +113,38 @@ template <> struct MathFast<double> {
         const double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
         const int e = __builtin_amdgcn_frexp_exp(x);     // x = m 2^e
         const unsigned hi = (unsigned)__double2hiint(m);
-        const unsigned off = (hi >> 8) & ((LOG_TAB_N - 1) << 4); // byte offset of entry (top 8 fraction bits)
+        // byte offset of the 16-byte entry: the top LOG_TAB_BITS fraction bits (hi[19 .. 20-BITS])
+        const unsigned off = (hi >> (20 - LOG_TAB_BITS - 4)) & ((LOG_TAB_N - 1) << 4);
         const double* ent = reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.log_tab) + off);
         const double invc = ent[0];
         const double l2c = ent[1];
-        const double r = __builtin_fma(m, invc, -1.0);   // |r| < 2^-8
-        // log2(1 + r) = r (c1 + r (c2 + ... r c6)),  c_k = (-1)^(k+1) / (k ln 2)
-        double p = __builtin_fma(r, -0.24044917348149393, c5v); // c6 r + c5
-        p = __builtin_fma(p, r, -0.36067376022224085);   // c4
-        p = __builtin_fma(p, r, 0.48089834696298783);    // c3
+        const double r = __builtin_fma(m, invc, -1.0);   // |r| <= 2^-12 (2^-11 in the first interval)
+        // log2(1 + r) = r (c1 + r (c2 + r (c3 + r c4))),  c_k = (-1)^(k+1) / (k ln 2)
+        double p = __builtin_fma(r, -0.36067376022224085, c3v); // c4 r + c3
         p = __builtin_fma(p, r, -0.72134752044448170);   // c2
         p = __builtin_fma(p, r, 1.4426950408889634);     // c1 = 1/ln2
         return __builtin_fma(r, p, (double)e + l2c);
     }
 
-    // 2^(u/128) for |u| < 2^50 (v_ldexp saturates to 0 / inf far inside that; the
+    // 2^(u/2048) for |u| < 2^50 (v_ldexp saturates to 0 / inf far inside that; the
     // closures' exponents are bounded by ~53 n/(n-1)); NaN in, NaN out.
     // k = rint(u) by the shifter trick (the low word of u + 1.5*2^52 is k), u - k in
-    // [-1/2, 1/2], 2^(j/128) from LDS, degree-5 polynomial in (u - k) with the 1/128^k
-    // folded into the coefficients.
+    // [-1/2, 1/2], 2^(j/2048) from LDS, degree-3 polynomial in (u - k) with the 1/2048^k
+    // folded into the coefficients (near-minimax: |error| < 9e-18 of the result).
     __device__ __forceinline__ double exp2_scaled(double u) const {
         const double sh = u + shiftv;
         const int k = __double2loint(sh);
         const double r = u - (sh - shiftv);                      // exact
         const unsigned off = ((unsigned)k << 3) & ((EXP_TAB_N - 1) << 3);
         const double tj = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
-        const int e = k >> 7;
-        // 2^(r/128) - 1 = r (q1' + r (q2' + ... r q5')),  q_k' = (ln2/128)^k / k!
-        double p = __builtin_fma(r, 1.3333558146428443e-3 / (128.0 * 128.0 * 128.0 * 128.0 * 128.0), q4v);
-        p = __builtin_fma(p, r, 5.5504108664821580e-2 / (128.0 * 128.0 * 128.0)); // q3'
-        p = __builtin_fma(p, r, 2.4022650695910071e-1 / (128.0 * 128.0));         // q2'
-        p = __builtin_fma(p, r, 6.9314718055994531e-1 / 128.0);                   // q1'
+        const int e = k >> EXP_TAB_BITS;
+        // 2^(r/2048) - 1 = r (q1 + r (q2 + r q3))
+        double p = __builtin_fma(r, 6.461528679825916e-12, q2v);
+        p = __builtin_fma(p, r, 0.0003384507717577858);
         const double res = __builtin_fma(tj, r * p, tj);
         return __builtin_amdgcn_ldexp(res, e);
     }
-    __device__ __forceinline__ double exp2_core(double t) const { return exp2_scaled(t * 128.0); }
+    __device__ __forceinline__ double exp2_core(double t) const { return exp2_scaled(t * EXP2_SCALE); }
 
     // x^y with libm's results for the special bases the closures can produce:
     // x == 0 (0 or inf by the sign of y), x < 0 or NaN (NaN; the reference raises
@@ -159,7 +162,7 @@ template <> struct MathFast<double> {
         return res;
     }
     __device__ __forceinline__ double exp(double x) const {
-        double res = exp2_scaled(x * (1.4426950408889634 * 128.0));
+        double res = exp2_scaled(x * (1.4426950408889634 * EXP2_SCALE));
         return (x != x) ? x : res;
     }
     // sqrt of a positive normal x: v_rsq_f64 seed, one coupled Newton step and a

@@ -35,12 +35,30 @@ constexpr bool f32_coupled_vgpr_constants() {
 
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false>
 constexpr int rhs_waves_per_simd() {
-    if (!M::is_production || FACTORS || PERCOL) return 1;
+    if (!M::is_production || FACTORS) return 1;
+    if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? 6 : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
+    if (PERCOL) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE) return LH_RHS_WAVES_PER_SIMD; // no ice ring: fits 64 VGPRs in every mode
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
     if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? 7 : 1;
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
+}
+
+// Threads per workgroup of the column kernel.  The Float64 production math stages 48 KiB of
+// log2/exp2 tables per workgroup (lh_fastmath.hpp), so a CU holds 3 such workgroups at most:
+// kernels that fit 64 VGPRs run 1024-thread workgroups (2 per CU = 8 waves/SIMD), the others
+// 512-thread ones (3 per CU = 6 waves/SIMD).  Everything else (Float32: hardware log/exp, the
+// libm debug policy) keeps 256.
+template <typename M, int WAVES>
+constexpr int rhs_max_threads() {
+    return M::uses_tables ? (WAVES >= 8 ? 1024 : 512) : 256;
+}
+// the waves-per-SIMD the compiler is asked to leave room for, given that workgroup size
+template <typename M, int WAVES>
+constexpr int rhs_min_waves() {
+    if (!M::uses_tables) return WAVES;
+    return WAVES >= 8 ? 8 : (WAVES >= 6 ? 6 : (WAVES >= 4 ? 4 : (WAVES >= 2 ? 2 : 1)));
 }
 
 // ----------------------------------------------------------------- helpers
@@ -173,7 +191,8 @@ __device__ __forceinline__ bool finite(FT x) {
 // d theta_i = 0 (right_hand_side.jl:182, :359) is never stored by any mode: the host side keeps
 // the theta_i plane of a tendency state zero (cleared once, tracked by the state's zero bits).
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false>
-__global__ void __launch_bounds__(256, (rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()))
+__global__ void __launch_bounds__((rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()),
+                                  (rhs_min_waves<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()))
 rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
@@ -410,14 +429,17 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             for (int j = 0; j < CPL; ++j) {
                 Fw[j] = Fe[j] = FT(0);
                 FT gh = FT(0);
+                // -1/2 (a_lo + a_hi) (x_hi - x_lo)/dz with the exact factor 1/2 folded into 1/dz:
+                // bitwise the three-multiply form (scaling by 2 commutes with rounding), one
+                // multiply less per term
                 if (WATER) {
-                    gh = (h[j] - h_p[j]) * P.inv_dz;
-                    Fw[j] = -((K_p[j] + K[j]) * FT(0.5)) * gh;
+                    gh = (h[j] - h_p[j]) * P.half_inv_dz;
+                    Fw[j] = -(K_p[j] + K[j]) * gh;
                 }
                 if (HEAT) {
-                    FT gT = (T[j] - T_p[j]) * P.inv_dz;
-                    Fe[j] = -((kap_p[j] + kap[j]) * FT(0.5)) * gT;
-                    if (WATER) Fe[j] = Fe[j] - ((E_p[j] + E[j]) * FT(0.5)) * gh;
+                    FT gT = (T[j] - T_p[j]) * P.half_inv_dz;
+                    Fe[j] = -(kap_p[j] + kap[j]) * gT;
+                    if (WATER) Fe[j] = Fe[j] - (E_p[j] + E[j]) * gh;
                 }
             }
             if (!SEG || i > i_lo) emit(Fw, Fe, vl_p, re_p); // cell i-1 belongs to this segment
@@ -507,6 +529,15 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
 // WAVE: a column is one wavefront (nlev <= 64).  The neighbour exchange then needs no
 // workgroup barrier -- LDS operations of one wave execute in order -- so a workgroup can hold
 // many columns (wide contiguous pieces for the plane tiles) without coupling their arithmetic.
+// exchange arrays per column / plane tiles of the initial fetch (the two share the dynamic LDS)
+template <int MODEL> constexpr int cs_exchange_arrays() {
+    return MODEL == MODEL_COUPLED ? 5 : 2;
+}
+static inline int cs_fetch_tiles(int model, bool noice, bool need_Taux) {
+    if (model == MODEL_RICHARDS) return 1 + (noice ? 0 : 1) + (need_Taux ? 2 : 0); // T sits in tile 3
+    return 3; // vl, ti, rhoe (HEAT reads the first two from Ya)
+}
+
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE, bool NOICE = false>
 __global__ void __launch_bounds__(1024)
 column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
@@ -522,9 +553,12 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const int slot = int(threadIdx.x) / tpc;
     const int cpb = int(blockDim.x) / tpc;
     const FT dt = dt_device ? *dt_device : dt_value;
-    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * 5 * n;
+    // exchange arrays of this column: (K, h) for the water, (T, kappa) for the heat, rho_e_l K for
+    // both -- only what the model needs (LDS per workgroup sets how many workgroups a CU holds)
+    constexpr int NARR = cs_exchange_arrays<MODEL>();
+    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * n;
     FT* sh = sK + n;
-    FT* sT = sh + n;
+    FT* sT = WATER ? sh + n : sK;
     FT* sKap = sT + n;
     FT* sE = sKap + n;
     const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
@@ -548,7 +582,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     // global memory sees the cpb adjacent columns of a level as one contiguous piece.  All
     // planes are requested before the one barrier (a block is short-lived when nsteps is
     // small: serialised round trips to HBM would dominate it).
-    FT* tiles = reinterpret_cast<FT*>(s_dyn); // up to 5 tiles [cpb][n], the exchange arrays' space
+    FT* tiles = reinterpret_cast<FT*>(s_dyn); // tiles [cpb][n] in the exchange arrays' space (tile k <= 3)
     const int64_t col_first = int64_t(blk) * cpb;
     const int tile_n = n * cpb;
     auto request = [&](const FT* plane, int k) {
@@ -613,14 +647,14 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                     Fe_lo = Fe_b;
                 } else {
                     FT gh = FT(0);
-                    if (WATER) {
-                        gh = (h - sh[i - 1]) * P.inv_dz;
-                        Fw_lo = -((sK[i - 1] + K) * FT(0.5)) * gh;
+                    if (WATER) { // (as rhs_kernel: the factor 1/2 folded into 1/dz)
+                        gh = (h - sh[i - 1]) * P.half_inv_dz;
+                        Fw_lo = -(sK[i - 1] + K) * gh;
                     }
                     if (HEAT) {
-                        const FT gT = (T - sT[i - 1]) * P.inv_dz;
-                        Fe_lo = -((sKap[i - 1] + kap) * FT(0.5)) * gT;
-                        if (WATER) Fe_lo = Fe_lo - ((sE[i - 1] + E) * FT(0.5)) * gh;
+                        const FT gT = (T - sT[i - 1]) * P.half_inv_dz;
+                        Fe_lo = -(sKap[i - 1] + kap) * gT;
+                        if (WATER) Fe_lo = Fe_lo - (sE[i - 1] + E) * gh;
                     }
                 }
                 if (at_top) {
@@ -633,13 +667,13 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 } else {
                     FT gh = FT(0);
                     if (WATER) {
-                        gh = (sh[i + 1] - h) * P.inv_dz;
-                        Fw_hi = -((K + sK[i + 1]) * FT(0.5)) * gh;
+                        gh = (sh[i + 1] - h) * P.half_inv_dz;
+                        Fw_hi = -(K + sK[i + 1]) * gh;
                     }
                     if (HEAT) {
-                        const FT gT = (sT[i + 1] - T) * P.inv_dz;
-                        Fe_hi = -((kap + sKap[i + 1]) * FT(0.5)) * gT;
-                        if (WATER) Fe_hi = Fe_hi - ((E + sE[i + 1]) * FT(0.5)) * gh;
+                        const FT gT = (sT[i + 1] - T) * P.half_inv_dz;
+                        Fe_hi = -(kap + sKap[i + 1]) * gT;
+                        if (WATER) Fe_hi = Fe_hi - (E + sE[i + 1]) * gh;
                     }
                 }
             }
@@ -944,7 +978,14 @@ static inline dim3 grid_for(int64_t work, int block) {
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, bool NOICE>
 static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                             const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
-                            int mode, int block, hipStream_t s) {
+                            int mode, int block_req, hipStream_t s) {
+    // workgroup size: the kernel's own (see rhs_max_threads) unless LH_TUNE block= asks for less
+    const int mode_k = M::is_production ? mode : 0;
+    int kmax = 256;
+#define LH_KMAX(MD) case MD: kmax = rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MD, NOICE && M::is_production>()>(); break;
+    switch (mode_k) { LH_KMAX(0) LH_KMAX(1) LH_KMAX(2) LH_KMAX(3) LH_KMAX(4) }
+#undef LH_KMAX
+    const int block = (block_req > 0 && block_req <= kmax) ? block_req : kmax;
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
     if (CFG::SEG) g.y = (unsigned)((P.nlev + P.seg_len - 1) / P.seg_len);
@@ -972,7 +1013,7 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
                              const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
                              int mode, bool factors, bool percol, bool noice, const Tune& tune, hipStream_t s) {
     using CFG = typename DefaultCfg<FT>::type;
-    const int block = tune.block > 0 ? tune.block : 256;
+    const int block = tune.block; // 0: the kernel's own workgroup size
 #ifdef LH_TUNING_VARIANTS
     // tuning builds: alternative columns-per-lane / prefetch depth for the plain tendency kernels
     if (!factors && !percol && mode == 0 && M::is_production && (tune.cpl > 0 || tune.pf > 0)) {
@@ -1044,10 +1085,18 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     // columns otherwise (64-byte pieces of every plane row: tile I/O 0.43 instead of 0.79 ms
     // on 1e6 x 64 Float64, tools/microbench/tile_io_probe.hip)
     const bool wave = tpc == 64;
+    // The Float64 math tables take 48 KiB of LDS per workgroup whatever its size, so large
+    // ensembles of Float64 columns run 512-thread workgroups (2 per CU; measured on 1e6 columns:
+    // 64 levels 0.75 / 0.68 / 0.78 ms per step with 256 / 512 / 1024 threads, 128 levels
+    // 1.65 / 1.51 / 1.80); Float32 (no tables) keeps 8 one-wave columns / 256 threads.
     unsigned cpb = wave ? 8u : (256u / tpc ? 256u / tpc : 1u);
+    if (sizeof(FT) == 8 && P.ncols >= 4096) cpb = 512u / tpc ? 512u / tpc : 1u;
     if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;
     dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
-    const unsigned dyn = (unsigned)(cpb * 5 * (size_t)P.nlev * sizeof(FT));
+    const bool need_Taux = (MODEL == MODEL_RICHARDS) && factors && P.viscosity_kind;
+    const int tiles = cs_fetch_tiles(MODEL, noice && !factors, need_Taux);
+    const int narr = cs_exchange_arrays<MODEL>();
+    const unsigned dyn = (unsigned)(cpb * (size_t)(narr > tiles ? narr : tiles) * (size_t)P.nlev * sizeof(FT));
     using M = MathFast<FT>;
 #define LH_CS(F, PC, NI)                                                                                          \
     do {                                                                                                          \

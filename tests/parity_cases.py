@@ -470,6 +470,12 @@ def closure_tolerances(case: Case, diag, Cw: float):
         t = np.where(S < 1, S ** (1.0 / m), 1.0)
         inner = np.where(S < 1, 1.0 - (1.0 - t) ** m, 1.0)
         condK = 1.0 + 2.0 / np.maximum(inner, 1e-300) + np.abs(np.log(np.maximum(S, 1e-300))) / m
+        # the inner cancellation w = 1 - S^(1/m): an eps-rounding of t = S^(1/m) (which the
+        # reference's own correctly rounded pow has) moves w by eps t / w relatively, and
+        # K ~ (1 - w^m)^2 by 2 m w^m / inner of that -- large next to saturation (t -> 1, w -> 0)
+        w = np.where(S < 1, 1.0 - t, 1.0)
+        condK = condK + np.where(S < 1, 2.0 * m * t * np.maximum(w, 1e-300) ** (m - 1.0)
+                                 / np.maximum(inner, 1e-300), 0.0)
         u = np.where(Se < 1, Se ** (-1.0 / m) - 1.0, 0.0)
         condpsi = np.where(Se < 1, 1.0 + (u + 1.0) / (n * np.maximum(u, 1e-300)) +
                            np.abs(np.log(np.maximum(Se, 1e-300))) / (m * n), 2.0)
