@@ -224,6 +224,20 @@ int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out
 int lh_step_ssprk33(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double dt,
                     int64_t nsteps, const double* bc_stage_values);
 
+/* One stage of that step (OrdinaryDiffEq SSPRK33, Shu-Osher form), for hosts that must refresh
+ * Ya between the stage evaluations: the reference's rhs! calls update_aux_en!/update_aux_hydr!
+ * with the STAGE time at every evaluation (right_hand_side.jl:37-42, 54-81), so a prescribed
+ * T_profile(z, t) / theta_l_profile(z, t) that really depends on t has to be re-evaluated by
+ * the host shim and uploaded three times per step:
+ *   stage 1 (time t):        U = Y + dt f(Y; Ya)
+ *   stage 2 (time t + dt):   U = (3 Y + U + dt f(U; Ya)) / 4
+ *   stage 3 (time t + dt/2): Y = (Y + 2 U + 2 dt f(U; Ya)) / 3
+ * U: a state with the model's prognostic planes (its theta_i plane is not used: theta_i is read
+ * from Y and never changes).  bc_values: NULL or [2][2] doubles (face, component) for this
+ * stage.  Three calls are bitwise one lh_step_ssprk33 step with the same Ya. */
+int lh_ssprk33_stage(lh_ctx*, int32_t stage, lh_state* Y, lh_state* U, const lh_state* Ya, double dt,
+                     const double* bc_values);
+
 /* Placement tuning -- no counterpart in the reference (host arrays have no such
  * effect).  The speed of the column launch on MI355X depends on where in HBM the
  * planes it streams together sit relative to each other (a few discrete rates,

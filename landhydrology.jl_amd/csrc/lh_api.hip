@@ -351,8 +351,9 @@ Planes<FT> planes_of(const lh_state* s) {
 template <typename FT>
 int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
            double dt, int mode, const double* bc_override, const void* dt_device = nullptr,
-           void* dt_out = nullptr) {
+           void* dt_out = nullptr, bool unsegmented = false) {
     DevParams<FT> P = make_params<FT>(c);
+    if (unsegmented) P.seg_len = 0; // an in-place stage must not be level-segmented
     P.dt_out = dt_out;
     P.xcd_remap = c->tune.xcd;
     if (bc_override)
@@ -1160,6 +1161,26 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     for (int64_t s = done; s < nsteps; ++s)
         if ((rc = one_step(bcv ? bcv + s * 12 : nullptr))) return rc;
     return LH_OK;
+}
+
+int lh_ssprk33_stage(lh_ctx* c, int32_t stage, lh_state* Y, lh_state* U, const lh_state* Ya, double dt,
+                     const double* bc_values) {
+    if (!c) return LH_EINVAL;
+    if (stage < 1 || stage > 3) return fail(c, LH_EINVAL, "lh_ssprk33_stage: stage must be 1, 2 or 3");
+    if (!(dt > 0)) return fail(c, LH_EINVAL, "lh_ssprk33_stage: need dt > 0");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, U, pm & ~LH_MASK(LH_VAR_THETA_I), "U"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    if (U == Y) return fail(c, LH_EINVAL, "lh_ssprk33_stage: U must not be Y");
+    (void)hipSetDevice(c->device);
+    // stage 1: U = Y + dt f(Y); 2: U = (3Y + U + dt f(U))/4; 3: Y = (Y + 2U + 2dt f(U))/3
+    const lh_state* in = stage == 1 ? Y : U;
+    lh_state* out = stage == 3 ? Y : U;
+    return c->cfg.dtype == LH_F64 ? do_rhs<double>(c, in, Ya, Y, out, dt, stage, bc_values, nullptr, nullptr, true)
+                                  : do_rhs<float>(c, in, Ya, Y, out, dt, stage, bc_values, nullptr, nullptr, true);
 }
 
 int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t,

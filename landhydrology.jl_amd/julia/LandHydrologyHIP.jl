@@ -18,6 +18,12 @@
 #   Y    = upload(ens, ϑ_l = A1, θ_i = A2)              # [nelements, ncolumns] arrays
 #   step_ssprk33!(ens, Y, nothing, t, dt, nsteps)
 #
+# One process per GPU, columns block-partitioned (block_range), global adaptive dt:
+#
+#   attach_comm!(ens, rank, nranks, id)                  # id = comm_unique_id() on rank 0, broadcast
+#   rhs_stable_dt!(ens, dY, Y, nothing, t, 0.5, dt_dev)  # dt_dev now holds the GLOBAL minimum
+#   step_ssprk33_device_dt!(ens, Y, nothing, t, dt_dev)
+#
 module LandHydrologyHIP
 
 using LandHydrology
@@ -31,8 +37,8 @@ using CLIMAParameters.Planet: ρ_cloud_liq, ρ_cloud_ice, cp_l, cp_i, T_0, LH_f0
 using CLIMAParameters.Atmos.Microphysics: K_therm
 import LandHydrology.SoilInterface: make_rhs
 
-export HIPBackend, ColumnEnsemble, upload, download, step_ssprk33!, stable_dt, rhs_stable_dt!,
-    step_ssprk33_device_dt!
+export HIPBackend, ColumnEnsemble, upload, download, device_rhs!, step_ssprk33!, stable_dt,
+    rhs_stable_dt!, step_ssprk33_device_dt!, block_range, comm_unique_id, attach_comm!, detach_comm!
 
 const lib = get(ENV, "LANDHYDRO_HIP_LIB", "liblandhydro_hip.so")
 
@@ -110,7 +116,15 @@ function ColumnEnsemble(model::SoilModel{FT}, ncolumns::Integer; backend = HIPBa
     rc = ccall((:lh_create, lib), Cint, (Ptr{Ptr{Cvoid}}, Ptr{lh_config}), ctx, cfg)
     rc == 0 || check(C_NULL, rc)
     ens = ColumnEnsemble{FT, typeof(model)}(ctx[], model, ncolumns)
-    finalizer(e -> ccall((:lh_destroy, lib), Cint, (Ptr{Cvoid},), e.ctx), ens)
+    # lh_destroy frees every state of the context too.  Julia runs finalizers in no particular
+    # order, so the handle is nulled here and a DeviceState finalized later skips lh_state_destroy
+    # (its `ens` field keeps this object alive until then).
+    finalizer(ens) do e
+        if e.ctx != C_NULL
+            ccall((:lh_destroy, lib), Cint, (Ptr{Cvoid},), e.ctx)
+            e.ctx = C_NULL
+        end
+    end
     ps = model.earth_param_set
     if ps !== nothing && !(model.energy_model isa PrescribedTemperatureModel)
         ep = Ref(lh_earth_params(ρ_cloud_liq(ps), ρ_cloud_ice(ps), cp_l(ps), cp_i(ps), T_0(ps),
@@ -162,13 +176,26 @@ function new_state(ens::ColumnEnsemble, mask::UInt32 = UInt32(0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ens.ctx, ccall((:lh_state_create, lib), Cint, (Ptr{Cvoid}, UInt32, Ptr{Ptr{Cvoid}}), ens.ctx, mask, h))
     st = DeviceState(ens, h[])
-    finalizer(s -> ccall((:lh_state_destroy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ens.ctx, s.handle), st)
+    finalizer(st) do s
+        # the context may already be gone (and with it this state): nothing left to free then
+        if s.ens.ctx != C_NULL && s.handle != C_NULL
+            ccall((:lh_state_destroy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ens.ctx, s.handle)
+        end
+        s.handle = C_NULL
+    end
     return st
 end
 
 # A is [nelements, ncolumns], column-major: level-fastest per column, exactly
 # `parent(field)` of the reference when ncolumns == 1 (coupled.jl:198-200).
 function upload!(st::DeviceState, var::Symbol, A::AbstractMatrix{FT}) where {FT}
+    if iszero(A)
+        # an all-zero field is a fill: the library then KNOWS the plane is zero and neither reads a
+        # zero θ_i plane nor re-stores dθ_i = 0
+        check(st.ens.ctx, ccall((:lh_state_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64),
+                                st.ens.ctx, st.handle, LH_VAR[var], 0.0))
+        return
+    end
     check(st.ens.ctx, ccall((:lh_upload, lib), Cint,
                             (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64),
                             st.ens.ctx, st.handle, LH_VAR[var], A, 1, size(A, 1)))
@@ -197,7 +224,7 @@ download(st::DeviceState, var::Symbol, ::Type{FT}) where {FT} =
     download!(Matrix{FT}(undef, st.ens.model.domain.nelements, st.ens.ncolumns), st, var)
 
 "rhs!(dY, Y, Ya, t) on device states (right_hand_side.jl:37-42)"
-function rhs!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t)
+function device_rhs!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t)
     set_bcs!(ens, t)
     ya = Ya === nothing ? C_NULL : Ya.handle
     check(ens.ctx, ccall((:lh_rhs, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
@@ -205,19 +232,78 @@ function rhs!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t)
     return dY
 end
 
-"solve(prob, SSPRK33(), dt = dt) for `nsteps` steps, state stays on the device (simulation.jl:58-87)"
-function step_ssprk33!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt, nsteps)
-    # Dirichlet closures at the stage times t, t+dt, t+dt/2 -> [4, 3, nsteps] doubles
+# Planes of Ya the DEVICE reads (the prescribed fields of make_update_aux, right_hand_side.jl:54-81):
+# (ϑ_l, θ_i) for a prescribed hydrology; T for a prescribed temperature only when a viscosity
+# factor consumes it (:160).  Mask bits as LH_MASK(var) of include/landhydro.h.
+function aux_mask(model::SoilModel)
+    model.hydrology_model isa PrescribedHydrologyModel && return UInt32(0b0011)
+    if model.energy_model isa PrescribedTemperatureModel &&
+       model.hydrology_model.viscosity_factor isa TemperatureDependentViscosity
+        return UInt32(0b1000)
+    end
+    return UInt32(0)
+end
+
+# the prescribed profiles at time t on the centre coordinates zc (a Vector), as [nelements, ncolumns]
+# matrices uploaded into the aux state Yad (every column the same profile: the reference's closures
+# are functions of (z, t) only)
+function upload_aux!(ens::ColumnEnsemble, Yad::DeviceState, zc::AbstractVector{FT}, t) where {FT}
+    m = ens.model
+    rep(v) = repeat(reshape(FT.(v), :, 1), 1, ens.ncolumns)
+    if m.hydrology_model isa PrescribedHydrologyModel
+        upload!(Yad, :ϑ_l, rep(m.hydrology_model.ϑ_l_profile.(zc, t)))
+        upload!(Yad, :θ_i, rep(m.hydrology_model.θ_i_profile.(zc, t)))
+    else
+        upload!(Yad, :T, rep(m.energy_model.T_profile.(zc, t)))
+    end
+    return Yad
+end
+
+coordinates(ens::ColumnEnsemble) = begin
+    zc = Vector{Float64}(undef, ens.model.domain.nelements)
+    check(ens.ctx, ccall((:lh_coordinates, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ens.ctx, zc))
+    zc
+end
+
+bc_stage_values(ens::ColumnEnsemble, ts) = begin
     bcs = ens.model.boundary_conditions
-    vals = Array{Float64}(undef, 2, 2, 3, nsteps)      # (component, face, stage, step), C order reversed
-    for s in 1:nsteps, (k, off) in enumerate((0.0, dt, dt / 2))
-        ts = t + (s - 1) * dt + off
-        for (f, fbc) in enumerate((bcs.bottom, bcs.top)), (c, bc) in enumerate((fbc.energy, fbc.hydrology))
-            vals[c, f, k, s] = bc_value(bc, ts)
+    vals = Array{Float64}(undef, 2, 2)                 # (component, face): C order [face][component]
+    for (f, fbc) in enumerate((bcs.bottom, bcs.top)), (c, bc) in enumerate((fbc.energy, fbc.hydrology))
+        vals[c, f] = bc_value(bc, ts)
+    end
+    vals
+end
+
+"""
+    step_ssprk33!(ens, Y, Ya, t, dt, nsteps; aux_depends_on_time = false)
+
+`solve(prob, SSPRK33(), dt = dt)` for `nsteps` steps, state stays on the device
+(simulation.jl:58-87).  `Ya` is `nothing` or the aux DeviceState (see `aux_mask`).  With
+`aux_depends_on_time` the prescribed profiles are re-evaluated and uploaded at every STAGE time,
+as the reference's rhs! does (right_hand_side.jl:37-42), one lh_ssprk33_stage launch per stage;
+otherwise all steps run in one lh_step_ssprk33 call with Ya as it is.
+"""
+function step_ssprk33!(ens::ColumnEnsemble{FT}, Y::DeviceState, Ya, t, dt, nsteps; aux_depends_on_time = false) where {FT}
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    if aux_depends_on_time && Ya !== nothing
+        zc = FT.(coordinates(ens))
+        U = new_state(ens)
+        for s in 1:nsteps, (stage, off) in enumerate((0.0, dt, dt / 2))
+            ts = t + (s - 1) * dt + off
+            upload_aux!(ens, Ya, zc, ts)
+            set_bcs!(ens, ts)
+            check(ens.ctx, ccall((:lh_ssprk33_stage, lib), Cint,
+                                 (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Float64}),
+                                 ens.ctx, Int32(stage), Y.handle, U.handle, ya, dt, bc_stage_values(ens, ts)))
         end
+        return Y
+    end
+    # Dirichlet closures at the stage times t, t+dt, t+dt/2 -> [nsteps][3][2][2] doubles in C order
+    vals = Array{Float64}(undef, 2, 2, 3, nsteps)      # (component, face, stage, step): column-major = C order reversed
+    for s in 1:nsteps, (k, off) in enumerate((0.0, dt, dt / 2))
+        vals[:, :, k, s] = bc_stage_values(ens, t + (s - 1) * dt + off)
     end
     set_bcs!(ens, t)
-    ya = Ya === nothing ? C_NULL : Ya.handle
     check(ens.ctx, ccall((:lh_step_ssprk33, lib), Cint,
                          (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Float64}),
                          ens.ctx, Y.handle, ya, t, dt, nsteps, vals))
@@ -285,24 +371,71 @@ function make_rhs(model::SoilModel{FT}, backend::HIPBackend) where {FT}
     update_aux_en! = LandHydrology.SoilInterface.make_update_aux(model.energy_model)
     update_aux_hydr! = LandHydrology.SoilInterface.make_update_aux(model.hydrology_model)
     Yd, dYd = new_state(ens), new_state(ens)
-    Yad = nothing
-    function rhs!(dY, Y, Ya, t)
-        update_aux_en!(Ya, t)
+    am = aux_mask(model)
+    Yad = am == 0 ? nothing : new_state(ens, am)
+    col(field) = reshape(parent(field), :, 1)          # one column, level-fastest (coupled.jl:198-200)
+    # (the closure has its own name: an inner `rhs!` would shadow nothing here, but a 4-argument
+    # local named like the 5-argument device method invites exactly that mistake)
+    function rhs_host!(dY, Y, Ya, t)
+        update_aux_en!(Ya, t)                          # right_hand_side.jl:38-39
         update_aux_hydr!(Ya, t)
         ys = getproperty(Y, model.name)
         for k in propertynames(ys)
-            upload!(Yd, k, reshape(parent(getproperty(ys, k)), :, 1))
+            upload!(Yd, k, col(getproperty(ys, k)))
         end
-        # prescribed fields the device reads: T (viscosity) or (ϑ_l, θ_i) (heat-only)
-        # are uploaded into Yad the same way from getproperty(Ya, model.name)
-        rhs!(ens, dYd, Yd, Yad, t)
+        if Yad !== nothing                             # the prescribed fields the device reads
+            ya = getproperty(Ya, model.name)
+            if model.hydrology_model isa PrescribedHydrologyModel
+                upload!(Yad, :ϑ_l, col(ya.ϑ_l))
+                upload!(Yad, :θ_i, col(ya.θ_i))
+            else
+                upload!(Yad, :T, col(ya.T))
+            end
+        end
+        device_rhs!(ens, dYd, Yd, Yad, t)
         ds = getproperty(dY, model.name)
         for k in propertynames(ds)
-            download!(reshape(parent(getproperty(ds, k)), :, 1), dYd, k)
+            download!(col(getproperty(ds, k)), dYd, k)
         end
-        return dY
+        return dY                                      # :41
     end
-    return rhs!
+    return rhs_host!
 end
+
+# ---- multi-GPU: block partition + the one collective (include/landhydro.h, SURVEY 8e) --------
+
+"columns [lo, hi) (0-based, half-open) owned by `rank` of `nranks`"
+function block_range(ncols_global::Integer, rank::Integer, nranks::Integer)
+    lo, hi = Ref{Int64}(0), Ref{Int64}(0)
+    rc = ccall((:lh_block_range, lib), Cint, (Int64, Int32, Int32, Ptr{Int64}, Ptr{Int64}),
+               ncols_global, rank, nranks, lo, hi)
+    rc == 0 || error("lh_block_range: bad arguments")
+    return lo[], hi[]
+end
+
+"ncclGetUniqueId: 128 bytes drawn on ONE rank; ship them to the others (e.g. MPI.Bcast!) before attach_comm!"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = ccall((:lh_comm_unique_id, lib), Cint, (Ptr{Cvoid},), id)
+    rc == 0 || check(C_NULL, rc)
+    return id
+end
+
+"""
+    attach_comm!(ens, rank, nranks, id)
+
+One process per GPU, each with its ColumnEnsemble over its block of columns: after this
+collective call `rhs_stable_dt!` and `stable_dt` deliver the GLOBAL minimum of the ranks' step
+bounds -- the library enqueues ncclAllReduce(count = 1, min) over RCCL/xGMI on its own stream.
+With MPI.jl: `id = rank == 0 ? comm_unique_id() : Vector{UInt8}(undef, 128); MPI.Bcast!(id, 0, comm)`.
+"""
+function attach_comm!(ens::ColumnEnsemble, rank::Integer, nranks::Integer, id::Vector{UInt8})
+    length(id) == 128 || error("the communicator id has 128 bytes")
+    check(ens.ctx, ccall((:lh_comm_init, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}),
+                         ens.ctx, rank, nranks, id))
+    return ens
+end
+detach_comm!(ens::ColumnEnsemble) =
+    check(ens.ctx, ccall((:lh_comm_destroy, lib), Cint, (Ptr{Cvoid},), ens.ctx))
 
 end # module

@@ -29,6 +29,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _ffi as F
+from .parameterizations import *  # noqa: F401,F403  (the exported SoilWater/SoilHeat helpers)
 
 Float32, Float64 = np.float32, np.float64
 
@@ -770,6 +771,54 @@ def _time_dependent(model):
     return False
 
 
+def _aux_time_dependent(model, Ya, t, dt) -> bool:
+    """Do the prescribed profiles the DEVICE reads change between t and the next stage times?
+    (Probed by evaluating the user's closures -- they are opaque callables -- at t, t + dt/2 and
+    t + dt on the model's own centre coordinates.)"""
+    be = model._backend()
+    if not _aux_mask(be.kind, model) or not isinstance(Ya, FieldVector):
+        return False
+    z = np.asarray(Ya.zc)
+    fns = []
+    if isinstance(model.energy_model, PrescribedTemperatureModel):
+        fns.append(model.energy_model.T_profile)
+    if isinstance(model.hydrology_model, PrescribedHydrologyModel):
+        fns += [model.hydrology_model.vartheta_l_profile, model.hydrology_model.theta_i_profile]
+    for f in fns:
+        a0 = np.asarray(f(z, t) + 0.0 * z)
+        for tt in (t + dt / 2, t + dt):
+            if not np.array_equal(a0, np.asarray(f(z, tt) + 0.0 * z)):
+                return True
+    return False
+
+
+def _advance_refreshing_aux(sim: Simulation, nsteps: int):
+    """SSPRK33 steps for prescribed profiles that depend on time: the reference's rhs! re-evaluates
+    them at EVERY stage time (update_aux_en!/update_aux_hydr!, right_hand_side.jl:37-42), so each
+    stage is its own launch (lh_ssprk33_stage) with Ya refreshed in between."""
+    it, model = sim.integrator, sim.model
+    be = model._backend()
+    L = F.lib()
+    update_en = make_update_aux(model.energy_model)
+    update_hy = make_update_aux(model.hydrology_model)
+    if getattr(it, "_stage_state", None) is None:
+        it._stage_state = it.u.similar()
+    U = it._stage_state
+    for _ in range(nsteps):
+        for stage, ts in ((1, it.t), (2, it.t + it.dt), (3, it.t + it.dt / 2)):
+            update_en(it.p, ts)
+            update_hy(it.p, ts)
+            vals = np.zeros((2, 2))
+            for (f, c), (kind, v) in be.bc_values(model, ts).items():
+                if np.ndim(v) == 0:
+                    vals[f, c] = float(v)
+            be.set_bcs(model, ts)       # kinds and per-column values
+            F.check(L.lh_ssprk33_stage(be.ctx, stage, it.u.handle, U.handle, it.p.handle, it.dt,
+                                       vals.ctypes.data_as(C.POINTER(C.c_double))), be.ctx)
+        it._nsteps_done += 1
+        it.t = it.t + it.dt
+
+
 def _advance(sim: Simulation, nsteps: int):
     it = sim.integrator
     model = sim.model
@@ -778,6 +827,12 @@ def _advance(sim: Simulation, nsteps: int):
     ya = it.p.handle if isinstance(it.p, FieldVector) else None
     if nsteps <= 0:
         return
+    if _aux_time_dependent(model, it.p, it.t, it.dt):
+        return _advance_refreshing_aux(sim, nsteps)
+    if _aux_mask(be.kind, model) and isinstance(it.p, FieldVector):
+        # constant-in-time profiles: still the values of THIS time (a user may have edited Ya)
+        make_update_aux(model.energy_model)(it.p, it.t)
+        make_update_aux(model.hydrology_model)(it.p, it.t)
     bcv = None
     if _time_dependent(model):
         t = it.t + it.dt * np.arange(nsteps)

@@ -121,3 +121,65 @@ def test_bench_input_generation_executes_nothing_of_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def _julia_ccalls(text):
+    """Every `ccall((:name, lib), Ret, (ArgTypes...), args...)` of the Julia shim ->
+    (name, ret, [argtypes]); the type tuple may span lines."""
+    import re
+    out = []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*lib\),\s*(\w+),\s*\(", text):
+        i, depth = m.end(), 1
+        while depth:                      # matching parenthesis of the type tuple
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        types = [t.strip() for t in re.split(r",(?![^{]*\})", text[m.end():i - 1]) if t.strip()]
+        out.append((m.group(1), m.group(2), types))
+    return out
+
+
+def test_julia_shim_ccalls_match_the_abi(pkg):
+    """Julia cannot run in this image, so the shim is checked as text: every ccall names an
+    exported symbol and passes the number, order and width of arguments the C ABI declares
+    (the header is checked against the same table in test_header_symbols_binding_agree)."""
+    F = pkg._ffi
+    path = os.path.join(g.PKG_DIR, "julia", "LandHydrologyHIP.jl")
+    text = open(path, encoding="utf-8").read()
+
+    def jl_kind(t):
+        if t.startswith("Ptr{") or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "UInt32": "u32", "Int64": "i64", "Float64": "f64",
+                "Cfloat": "f32"}[t]
+
+    def c_kind(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or issubclass(t, C._Pointer):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int32: "i32", C.c_uint32: "u32", C.c_int64: "i64",
+                C.c_double: "f64", C.c_float: "f32"}[t]
+
+    calls = _julia_ccalls(text)
+    assert len(calls) >= 25
+    seen = set()
+    for name, ret, types in calls:
+        assert name in F.SIGNATURES, f"the shim calls {name}, which the ABI does not declare"
+        res, args = F.SIGNATURES[name]
+        assert jl_kind(ret) == c_kind(res), (name, ret)
+        assert [jl_kind(t) for t in types] == [c_kind(a) for a in args], (name, types)
+        seen.add(name)
+    # the entry points a drop-in needs are all bound
+    for must in ("lh_create", "lh_destroy", "lh_last_error", "lh_set_earth_params", "lh_set_soil_params",
+                 "lh_set_vg_params", "lh_set_conductivity_factors", "lh_set_bc", "lh_state_create",
+                 "lh_state_destroy", "lh_upload", "lh_download", "lh_state_fill", "lh_rhs",
+                 "lh_rhs_stable_dt", "lh_step_ssprk33", "lh_ssprk33_stage", "lh_step_ssprk33_device_dt",
+                 "lh_stable_dt", "lh_coordinates", "lh_block_range", "lh_comm_unique_id", "lh_comm_init",
+                 "lh_comm_destroy"):
+        assert must in seen, f"the Julia shim never calls {must}"
+    # the closure of make_rhs does not shadow the device method, and uploads the aux fields
+    body = text[text.index("function make_rhs(model::SoilModel{FT}, backend::HIPBackend)"):]
+    assert "function rhs!(" not in body and "device_rhs!(ens, dYd, Yd, Yad, t)" in body
+    assert "upload!(Yad, :T" in body and "upload!(Yad, :ϑ_l" in body and "aux_mask(model)" in body
+    # finalizers: a state never calls into a destroyed context
+    assert "s.ens.ctx != C_NULL" in text and "e.ctx = C_NULL" in text

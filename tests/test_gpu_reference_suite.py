@@ -7,7 +7,7 @@ import math
 import numpy as np
 import pytest
 
-import __graft_entry__ as g
+import __graft_entry__ as g  # noqa: F401
 import case_model as M
 import parity_cases as pc
 
@@ -246,3 +246,91 @@ def test_error_behaviour(lh):
         lh.SoilModel(np.float32, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
                      hydrology_model=lh.SoilHydrologyModel(np.float32),
                      boundary_conditions=lh.SoilColumnBC(), earth_param_set=None)
+
+
+def _oracle_ssprk33_refreshing_aux(om, vl, ti, dt, nsteps, T_of, t0=0.0):
+    """SSPRK33 with the prescribed temperature re-evaluated at every STAGE time, as the
+    reference's rhs! does (right_hand_side.jl:37-42): the oracle's rhs driven stage by stage."""
+    f = lambda v, T: pc.O.rhs(om, v, ti, None, T)["vl"]
+    t = t0
+    y = vl.copy()
+    for _ in range(nsteps):
+        u1 = y + dt * f(y, T_of(t))
+        u2 = (3.0 * y + u1 + dt * f(u1, T_of(t + dt))) * 0.25
+        y = (y + 2.0 * u2 + 2.0 * dt * f(u2, T_of(t + dt / 2))) / 3.0
+        t += dt
+    return y
+
+
+def test_time_dependent_prescribed_temperature_is_refreshed_every_stage(lh):
+    """a T_profile(z, t) that depends on t must reach the device at every stage time
+    (Richards + TemperatureDependentViscosity reads Ya.soil.T on the device)."""
+    FT = np.float64
+    n, N = 40, 3
+    hm = lh.vanGenuchten(FT, n=2.0, α=2.6, Ksat=0.0443 / 3600 / 100, θr=0.0)
+    domain = lh.Column(FT, zlim=(-2.0, 0.0), nelements=n, ncolumns=N)
+    tau = 4000.0
+    Tp = lambda z, t: 283.0 + 12.0 * np.sin(t / tau) + 2.0 * z
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.VerticalFlux(-2e-8)),
+                         bottom=lh.SoilComponentBC(hydrology=lh.FreeDrainage()))
+    model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(T_profile=Tp),
+                         hydrology_model=lh.SoilHydrologyModel(
+                             FT, hydraulic_model=hm, viscosity_factor=lh.TemperatureDependentViscosity(FT)),
+                         boundary_conditions=bc, soil_param_set=lh.SoilParams(FT, ν=0.5),
+                         earth_param_set=lh.EarthParameterSet())
+    ic = lambda z, m: {"ϑ_l": 0.25 + 0.1 * np.sin(3.0 * z), "θ_i": 0.0 * z}
+    Y, Ya = lh.initialize_states(model, ic, 0.0)
+    dt, nsteps = 600.0, 12
+    sim = lh.Simulation(model, lh.SSPRK33(), Y_init=Y, dt=dt, tspan=(0.0, dt * nsteps), Ya_init=Ya)
+    lh.run(sim)
+    got = sim.integrator.u.soil.ϑ_l
+    zc = np.asarray(Ya.zc, dtype=FT)
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -2.0, 0.0, soil=M.default_soil(nu=0.5),
+                     vg=M.default_vg(n=2.0, alpha=2.6, Ksat=0.0443 / 3600 / 100, theta_r=0.0),
+                     bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_FLUX, -2e-8),
+                         (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)},
+                     cf=M.default_cf(viscosity=True))
+    vl0 = np.repeat((0.25 + 0.1 * np.sin(3.0 * zc))[None, :], N, axis=0)
+    ti0 = np.zeros_like(vl0)
+    T_of = lambda t: np.repeat(np.asarray(Tp(zc, t))[None, :], N, axis=0)
+    want = _oracle_ssprk33_refreshing_aux(om, vl0, ti0, dt, nsteps, T_of)
+    assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want))
+    # a stale (initial-time) temperature gives a visibly different answer: the refresh matters
+    stale = _oracle_ssprk33_refreshing_aux(om, vl0, ti0, dt, nsteps, lambda t: T_of(0.0))
+    assert np.max(np.abs(stale - want)) > 1e-6 * np.max(np.abs(want))
+    assert np.max(np.abs(want - vl0)) > 1e-4          # and the state moved
+    model.close()
+
+
+def test_hydrostatic_equilibrium_setup_with_the_exported_helpers(lh):
+    """The reference's own equilibrium checks use its exported helpers (hydrostatic_profile,
+    inverse_matric_potential: test_water_parameterizations.jl:16-21, 49-54); a hydrostatic
+    column has no interior flux, so with zero-flux faces the tendency vanishes to rounding."""
+    FT = np.float64
+    hm = lh.vanGenuchten(FT, n=2.0, α=2.6, Ksat=1e-6, θr=0.05)
+    nu, S_s, n = 0.5, 1e-3, 50
+    domain = lh.Column(FT, zlim=(-1.0, 0.0), nelements=n)
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0)),
+                         bottom=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0)))
+    model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                         hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                         boundary_conditions=bc, soil_param_set=lh.SoilParams(FT, ν=nu, S_s=S_s),
+                         earth_param_set=lh.EarthParameterSet())
+    ic = lambda z, m: {"ϑ_l": lh.hydrostatic_profile(hm, z, -0.6, nu, S_s), "θ_i": 0.0 * z}
+    Y, Ya = lh.initialize_states(model, ic, 0.0)
+    dY = Y.similar()
+    lh.make_rhs(model)(dY, Y, Ya, 0.0)
+    vl = Y.soil.ϑ_l[0]
+    zc = np.asarray(Ya.zc)
+    assert np.any(vl > nu) and np.any(vl < nu)                       # both zones present
+    # psi + z is constant in a hydrostatic column: h = z_interface
+    psi = lh.pressure_head(hm, vl, nu, S_s)
+    assert np.allclose(psi + zc, -0.6, rtol=0, atol=1e-12)
+    S = lh.effective_saturation(nu, vl[vl < nu], hm.theta_r)
+    assert np.allclose(lh.inverse_matric_potential(hm, lh.matric_potential(hm, S)), S, rtol=1e-12)
+    K = lh.hydraulic_conductivity(hm, lh.effective_saturation(nu, vl, hm.theta_r))
+    # rounding of the heads: eps (|psi| + |z|), and eps nu / S_s in the saturated zone, where
+    # psi = (vartheta_l - nu) / S_s amplifies the rounding of vartheta_l a thousandfold
+    bound = 64 * np.finfo(FT).eps * np.max(K) * (np.max(np.abs(psi)) + 1.0 + nu / S_s) / (1.0 / n) ** 2
+    assert np.max(np.abs(dY.soil.ϑ_l[0])) <= bound
+    model.close()

@@ -385,3 +385,148 @@ def test_fused_rhs_stable_dt(name):
     rel = 1e-11 if case.dtype == np.float64 else 2e-4
     assert abs(got - want_dt) <= rel * want_dt, (name, got, want_dt)
     assert abs(got - sep.value) <= rel * want_dt, (name, got, sep.value)
+
+
+# ------------------------------------------------------ the Float32 theta(z,t) bound
+def _as_f64_problem(case32):
+    """The same problem in Float64: the Float32-rounded inputs AND parameters (FT(x) of the model
+    constructors), so that what differs from the Float32 runs is the arithmetic alone."""
+    import dataclasses
+    r = lambda x: float(np.float32(x))
+    rd = lambda obj: dataclasses.replace(obj, **{f.name: r(getattr(obj, f.name))
+                                                  for f in dataclasses.fields(obj)
+                                                  if isinstance(getattr(obj, f.name), float)})
+    om = case32.om
+    om64 = dataclasses.replace(om, earth=rd(om.earth), soil=rd(om.soil), vg=rd(om.vg), cf=rd(om.cf),
+                               zmin=r(om.zmin), zmax=r(om.zmax),
+                               bc={k: (kind, r(v)) for k, (kind, v) in om.bc.items()})
+    up = lambda a: None if a is None else a.astype(np.float64)
+    return dataclasses.replace(case32, om=om64, dtype=np.float64, vl=up(case32.vl), ti=up(case32.ti),
+                               rhoe=up(case32.rhoe), T_aux=up(case32.T_aux))
+
+
+F32_BOUND_RESULTS = {}
+
+
+@pytest.mark.parametrize("name,nsteps", [("c3_coupled_f32", 30), ("c2_richards_f32", 40),
+                                         ("mixed_smooth_f32", 20)])
+def test_f32_theta_zt_is_as_close_to_f64_as_the_reference_arithmetic_is(name, nsteps):
+    """north_star: theta(z,t) within 1e-6 relative of the reference.  In Float32 the reference's
+    OWN arithmetic is not that close to the exact trajectory: this test measures three states
+    after the same steps -- HIP Float32 (H32), the oracle in Float32 (O32 = the reference's
+    arithmetic, pow for pow) and the oracle in Float64 on the Float32-rounded problem (O64) -- and
+    asserts that the HIP path is no farther from O64 than 1.5 x the reference arithmetic is:
+        max|H32 - O64| <= 1.5 max|O32 - O64|      per prognostic field.
+    The distances are printed (and recorded in BASELINE.md): they are the Float32 tolerance
+    statement for BASELINE config C3."""
+    case32 = pc.make_case(name)
+    case64 = _as_f64_problem(case32)
+    dt = float(np.float32(stable_dt(case32)))
+    H32 = gpu_steps(case32, dt, nsteps)
+    O32 = cpu_steps(case32, dt, nsteps)
+    O64 = cpu_steps(case64, dt, nsteps)
+    rec = {}
+    for k in O64:
+        if k == "ti":
+            assert np.array_equal(H32[k], case32.ti)            # theta_i never moves
+            continue
+        w = O64[k]
+        scale = np.max(np.abs(w))
+        dH = float(np.max(np.abs(H32[k].astype(np.float64) - w)) / scale)
+        dO = float(np.max(np.abs(O32[k].astype(np.float64) - w)) / scale)
+        dHO = float(np.max(np.abs(H32[k].astype(np.float64) - O32[k].astype(np.float64))) / scale)
+        rec[k] = {"H32_vs_O64": dH, "O32_vs_O64": dO, "H32_vs_O32": dHO}
+        assert dO > 0 and dH <= 1.5 * dO, (name, k, rec[k])
+        # and the state moved: the comparison is not vacuous
+        ref0 = getattr(case64, "vl" if k == "vl" else "rhoe")
+        assert np.max(np.abs(w - ref0)) > 100 * dO * scale, (name, k)
+    F32_BOUND_RESULTS[name] = rec
+    print(f"\nF32_BOUND {name} steps={nsteps} dt={dt:.6g} " + " ".join(
+        f"{k}: H32-O64={v['H32_vs_O64']:.3g} O32-O64={v['O32_vs_O64']:.3g} H32-O32={v['H32_vs_O32']:.3g}"
+        for k, v in rec.items()))
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "f32_bound.json"), "w") as fh:
+            json.dump(F32_BOUND_RESULTS, fh, indent=1)
+
+
+# --------------------------------- property pins for the BC branches no reference vector covers
+def _rhs_vl(case):
+    return pc.run_gpu_rhs(case)["vl"]
+
+
+def test_free_drainage_uniform_column_has_a_still_bottom_cell():
+    """boundary_conditions.jl:328-356: FreeDrainage sets the bottom flux to -K(centre state).
+    In a column of uniform vartheta_l every interior face carries -K as well (unit head gradient),
+    so the bottom cell's tendency vanishes (to the rounding of (psi + z_1) - (psi + z_0) = dz),
+    whatever the top does; with a zero-flux top the top cell drains at exactly K/dz.  BASELINE C5's
+    bottom boundary, pinned by property."""
+    n, N = 64, 130
+    c = np.arange(N)
+    vg_n = 1.4 + 2.6 * pc.uhash(c, 2, n)
+    Ksat = 10.0 ** (-7.0 + 3.0 * pc.uhash(c, 4, n))
+    nu = 0.3 + 0.25 * pc.uhash(c, 6, n)
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -1.28, 0.0,
+                     bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_FLUX, 0.0),
+                         (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FREE_DRAINAGE, 0.0)},
+                     percol=dict(vg_n=vg_n, vg_Ksat=Ksat, nu=nu))
+    vl = np.repeat((0.6 * nu)[:, None], n, axis=1)
+    case = pc.Case("fd_uniform", om, np.float64, N, vl=vl, ti=np.zeros((N, n)))
+    d = _rhs_vl(case)
+    diag = pc.run_gpu_diagnostics(case)
+    K = diag["K"][:, 0]
+    dz = 1.28 / n
+    eps = np.finfo(np.float64).eps
+    assert np.all(K > 0)
+    # interior cells and the bottom cell: |d| <= rounding of the head difference
+    bound = 8 * eps * K * (np.abs(diag["psi"][:, 0]) + 1.28) / dz / dz
+    assert np.all(np.abs(d[:, :-1]) <= bound[:, None])
+    # the top cell: -(0 - (-K))/dz
+    assert np.allclose(d[:, -1], -K / dz, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("consistent", [True, False])
+def test_dirichlet_hydrostatic_column(consistent):
+    """Dirichlet-as-flux, boundary_conditions.jl:371-401 (BASELINE C1's boundaries).  A hydrostatic
+    column whose two Dirichlet face values are the hydrostatic face values has zero flux through
+    every face when the bottom sign is the consistent one (lh_set_bottom_sign_consistent(1)):
+    |d vartheta_l| <= rounding everywhere.  As the reference WRITES the bottom face
+    (:395-398: the whole expression is negated, gravity term included) the bottom flux is
+    -K_f (psi_f - psi_c + dz/2)/(dz/2) negated = +2 K_f for a hydrostatic pair, so the bottom
+    cell alone gets -(0 - 2 K_f)/dz = +2 K_f/dz: the closed form of the quirk, on the device."""
+    import __graft_entry__ as ge
+    P = ge.load_package().parameterizations
+    lh = ge.load_package()
+    n = 64
+    zmin, zmax, zi = -1.28, 0.0, -2.0                     # water table below the column: all unsaturated
+    hm = lh.vanGenuchten(np.float64)                      # loam defaults
+    nu, S_s = 0.43, 1e-3
+    zc, zf = pc.grid_np(zmin, zmax, n)
+    vl = P.hydrostatic_profile(hm, zc, zi, nu, S_s)[None, :]
+    top = float(P.hydrostatic_profile(hm, np.float64(zmax), zi, nu, S_s))
+    bot = float(P.hydrostatic_profile(hm, np.float64(zmin), zi, nu, S_s))
+    om = M.CaseModel(M.MODEL_RICHARDS, n, zmin, zmax,
+                     bc={(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, top),
+                         (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, bot)},
+                     consistent_bottom_sign=consistent)
+    case = pc.Case("dirichlet_hydrostatic", om, np.float64, 1, vl=vl, ti=np.zeros((1, n)))
+    d = _rhs_vl(case)[0]
+    diag = pc.run_gpu_diagnostics(case)
+    K, psi = diag["K"][0], diag["psi"][0]
+    dz = (zmax - zmin) / n
+    eps = np.finfo(np.float64).eps
+    # hydrostatic: psi + z is the water-table height at every centre
+    assert np.allclose(psi + zc, zi, rtol=0, atol=1e-12)
+    # rounding bound of one face flux: K * (eps-level error of the head difference) / dz;
+    # the head values are O(|psi| + |z|)
+    face_err = 16 * eps * np.max(K) * (np.max(np.abs(psi)) + abs(zmin)) / (dz / 2)
+    if consistent:
+        assert np.max(np.abs(d)) <= 2 * face_err / dz
+    else:
+        K_f = float(P.hydraulic_conductivity(hm, P.effective_saturation(nu, np.float64(bot), 0.0)))
+        assert np.max(np.abs(d[1:])) <= 2 * face_err / dz
+        assert d[0] == pytest.approx(2.0 * K_f / dz, rel=1e-9)
+    # the oracle says the same, cell for cell
+    pc.assert_tendencies_close(case, {"vl": d[None, :], "ti": np.zeros((1, n))}, pc.run_oracle_rhs(case), 4.0)
