@@ -131,6 +131,17 @@ typedef struct {
     double n, alpha, theta_r, Ksat;
 } lh_vg_params;
 
+/* PrescribedAtmosForcing{FT} (boundary_conditions.jl:119-132: the first six fields), the
+ * roughness lengths it reads from SoilParams (parameters.jl:38-41), and the CLIMAParameters
+ * constants compute_turbulent_surface_fluxes (:553-620) consumes on top of lh_earth_params
+ * (Planet: R_v, R_d, grav, cp_d, cp_v, LH_v0, T_triple, press_triple; SubgridScale:
+ * von_karman_const).  Inputs, never kernel literals. */
+typedef struct {
+    double u_atm, theta_atm, z_atm, theta_scale, rho_a_sfc, q_atm;
+    double z_0m, z_0s;
+    double R_v, R_d, grav, cp_d, cp_v, LH_v0, T_triple, press_triple, von_karman;
+} lh_atmos_forcing;
+
 /* ---- lifetime ------------------------------------------------------------ */
 
 /* SoilModel(FT; domain, energy_model, hydrology_model, ...) (models.jl:115-135).
@@ -160,6 +171,25 @@ int lh_set_conductivity_factors(lh_ctx*, int32_t viscosity_kind, double gamma, d
  * percol_values (ncols doubles) overrides value per column when not NULL. */
 int lh_set_bc(lh_ctx*, int32_t face, int32_t component, int32_t kind, double value,
               const double* percol_values);
+/* SoilColumnBC(top = PrescribedAtmosForcing{FT}(...), bottom = ...) (boundary_conditions.jl:
+ * 119-161, 516-533): the TOP face of every column is driven by Monin-Obukhov surface fluxes
+ * computed on the device from the top cell's (vartheta_l, theta_i, T) before every tendency
+ * evaluation (compute_turbulent_surface_fluxes, :553-620; kernel in csrc/lh_atmos.hpp); the top
+ * entries of lh_set_bc are ignored while it is set.  Only LH_MODEL_COUPLED has a method
+ * (SoilEnergyModel + SoilHydrologyModel; LH_EMODEL otherwise, like the reference's MethodError),
+ * and only the top face (:523-528).  forcing == NULL removes it.  percol: NULL, or [3][ncols]
+ * doubles overriding u_atm, theta_atm, q_atm per column (build extension).  Where the
+ * Monin-Obukhov system has no root the fluxes are NaN and bit 1 of lh_get_status is set.
+ * PARITY UNPINNED beyond the reference's equilibrium invariant
+ * (test/SoilModel/test_prescribed_atmos_bc.jl:75-79): SurfaceFluxes.jl / Thermodynamics.jl are
+ * not part of the reference tree. */
+int lh_set_atmos_forcing(lh_ctx*, const lh_atmos_forcing* forcing, const double* percol);
+/* compute_turbulent_surface_fluxes.(energy, hydrology, model, vartheta_l, theta_i, T) for n
+ * top-cell states given as host arrays of doubles (as test_prescribed_atmos_bc.jl:92-100 calls
+ * it): heat_flux[n] and water_flux[n] (volume flux, positive upward) in doubles.  Scalar soil
+ * and forcing parameters of the context; evaluated on the device.  Synchronises. */
+int lh_atmos_surface_fluxes(lh_ctx*, int64_t n, const double* vartheta_l, const double* theta_i,
+                            const double* T, double* heat_flux, double* water_flux);
 /* 0 (default): bottom-face hydrology Dirichlet flux exactly as the reference
  * writes it (boundary_conditions.jl:395-398); 1: physically consistent sign. */
 int lh_set_bottom_sign_consistent(lh_ctx*, int32_t flag);
@@ -310,7 +340,8 @@ int lh_allreduce_min(lh_ctx*, void* value_device_ft);
 /* ---- status / timing -------------------------------------------------------- */
 
 /* bit 0: a non-finite tendency was produced since the last call (the reference
- * would have raised DomainError from `^`); synchronises and clears. */
+ * would have raised DomainError from `^`); bit 1: the Monin-Obukhov system of the
+ * prescribed-atmosphere BC had no root in some column; synchronises and clears. */
 int lh_get_status(lh_ctx*, uint32_t* flags);
 int lh_synchronize(lh_ctx*);
 /* Streaming ceiling of the column launch on a given set of planes (measurement aid, no

@@ -13,7 +13,8 @@ from .soil import (Column, Dirichlet, EarthParameterSet, FieldVector, Float32, F
                    FreeDrainage, IceImpedance, NoBC, NoEffect, PrescribedAtmosForcing,
                    PrescribedHydrologyModel, PrescribedTemperatureModel, Simulation,
                    SoilColumnBC, SoilComponentBC, SoilEnergyModel, SoilHydrologyModel, SoilModel,
-                   SoilParams, SSPRK33, TemperatureDependentViscosity, VerticalFlux, coordinates,
+                   SoilParams, SSPRK33, TemperatureDependentViscosity, VerticalFlux, boundary_fluxes,
+                   compute_turbulent_surface_fluxes, coordinates,
                    default_initial_conditions, initialize_states, make_function_space, make_rhs,
                    make_update_aux, run, stable_dt, step, tune_placement, vanGenuchten)
 

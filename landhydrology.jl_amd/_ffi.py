@@ -52,6 +52,13 @@ class lh_vg_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("n", "alpha", "theta_r", "Ksat")]
 
 
+class lh_atmos_forcing(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("u_atm", "theta_atm", "z_atm", "theta_scale", "rho_a_sfc", "q_atm", "z_0m", "z_0s",
+                 "R_v", "R_d", "grav", "cp_d", "cp_v", "LH_v0", "T_triple", "press_triple",
+                 "von_karman")]
+
+
 # every symbol include/landhydro.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -67,6 +74,8 @@ SIGNATURES = {
     "lh_set_conductivity_factors": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                               C.c_double]),
     "lh_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _DP]),
+    "lh_set_atmos_forcing": (C.c_int, [_P, C.POINTER(lh_atmos_forcing), _DP]),
+    "lh_atmos_surface_fluxes": (C.c_int, [_P, C.c_int64, _DP, _DP, _DP, _DP, _DP]),
     "lh_set_bottom_sign_consistent": (C.c_int, [_P, C.c_int32]),
     "lh_set_math_mode": (C.c_int, [_P, C.c_int32]),
     "lh_set_tuning": (C.c_int, [_P, C.c_char_p]),

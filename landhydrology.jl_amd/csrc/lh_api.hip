@@ -37,6 +37,8 @@ struct HostParams {
     int32_t bc_kind[2][2] = {{0, 0}, {0, 0}};
     double bc_value[2][2] = {{0, 0}, {0, 0}};
     int32_t consistent_bottom_sign = 0;
+    bool atmos_on = false;
+    lh_atmos_forcing atmos{};
 };
 
 } // namespace
@@ -77,6 +79,8 @@ struct lh_ctx {
     void* d_bc_pc[2][2] = {};          // FT[ncols] or null
     uint32_t* d_status = nullptr;
     void* d_dt = nullptr;              // FT scratch for lh_stable_dt
+    void* d_atm_pc[3] = {};            // per-column u_atm / theta_atm / q_atm (FT[ncols]) or null
+    void* d_atm_flux[2] = {};          // the top-face fluxes of the prescribed atmosphere: heat, water (FT[ncols])
     double* d_math_tab = nullptr;      // log2/exp2 tables of MathFast<double>
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
     lh_state* scratch_u2 = nullptr;    // second stage state (level-segmented launches cannot update U1 in place)
@@ -249,6 +253,8 @@ DevParams<FT> make_params(const lh_ctx* c) {
             P.bc_value[f][k] = FT(h.bc_value[f][k]);
             P.bc_pc[f][k] = static_cast<const FT*>(c->d_bc_pc[f][k]);
         }
+    if (h.atmos_on) // the top face is the prescribed atmosphere: a (per-column) flux once evaluated
+        P.bc_kind[LH_FACE_TOP][LH_COMP_ENERGY] = P.bc_kind[LH_FACE_TOP][LH_COMP_HYDROLOGY] = LH_BC_FLUX;
     P.consistent_bottom_sign = h.consistent_bottom_sign;
     P.status = c->d_status;
     P.math_tab = c->d_math_tab;
@@ -257,6 +263,38 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.seg_len = segment_length(c);
     P.cs_cpb = c->tune.cpb;
     return P;
+}
+
+template <typename FT>
+AtmosParams<FT> make_atmos_params(const lh_ctx* c) {
+    const lh_atmos_forcing& a = c->hp.atmos;
+    AtmosParams<FT> A;
+    memset(&A, 0, sizeof A);
+    A.u_atm = FT(a.u_atm);
+    A.theta_atm = FT(a.theta_atm);
+    A.z_atm = FT(a.z_atm);
+    A.theta_scale = FT(a.theta_scale);
+    A.rho_a_sfc = FT(a.rho_a_sfc);
+    A.q_atm = FT(a.q_atm);
+    A.z_0m = FT(a.z_0m);
+    A.z_0s = FT(a.z_0s);
+    A.R_v = FT(a.R_v);
+    A.R_d = FT(a.R_d);
+    A.grav = FT(a.grav);
+    A.cp_d = FT(a.cp_d);
+    A.cp_v = FT(a.cp_v);
+    A.T_triple = FT(a.T_triple);
+    A.press_triple = FT(a.press_triple);
+    A.von_karman = FT(a.von_karman);
+    A.cp_l = FT(c->hp.earth.cp_l);
+    A.T_0 = FT(c->hp.earth.T_0);
+    A.rho_liq = FT(c->hp.earth.rho_liq);
+    A.cp_v_d = a.cp_v;
+    A.LH_v0_d = a.LH_v0;
+    A.pc_u = static_cast<const FT*>(c->d_atm_pc[0]);
+    A.pc_theta = static_cast<const FT*>(c->d_atm_pc[1]);
+    A.pc_q = static_cast<const FT*>(c->d_atm_pc[2]);
+    return A;
 }
 
 // "block=128,pf=2,nt=1,cpl=2": launch-shape overrides (lh_launch.hpp, Tune)
@@ -309,7 +347,10 @@ uint32_t aux_mask(const lh_ctx* c) {
 int validate_model(lh_ctx* c) {
     const HostParams& h = c->hp;
     const int m = c->cfg.model;
+    if (h.atmos_on && m != LH_MODEL_COUPLED) // compute_turbulent_surface_fluxes has one method (:553-560)
+        return fail(c, LH_EMODEL, "PrescribedAtmosForcing needs SoilEnergyModel + SoilHydrologyModel (no method for this model)");
     for (int f = 0; f < 2; ++f) {
+        if (f == LH_FACE_TOP && h.atmos_on) continue; // the whole top face is the prescribed atmosphere
         const int ke = h.bc_kind[f][LH_COMP_ENERGY], kh = h.bc_kind[f][LH_COMP_HYDROLOGY];
         const char* fn = f == LH_FACE_TOP ? "top" : "bottom";
         if (ke == LH_BC_FREE_DRAINAGE)
@@ -362,6 +403,21 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
     const bool tend = mode == 0 || mode == 4;
     const uint32_t ti_bit = LH_MASK(LH_VAR_THETA_I);
+    if (c->hp.atmos_on) {
+        // boundary_fluxes(X, bc::PrescribedAtmosForcing, :top, ...) (:516-533): the surface fluxes of
+        // the state this evaluation reads, from its top cells, into the per-column flux arrays the
+        // column kernel takes as VerticalFlux values at the top face
+        const size_t top = size_t(c->cfg.nlev - 1) * size_t(c->stride);
+        const lh_state* ti_state = tend ? in : base; // fused stages keep theta_i in the base state
+        const FT* vl_top = static_cast<const FT*>(in->plane[LH_VAR_VARTHETA_L]) + top;
+        const FT* ti_top = static_cast<const FT*>(ti_state->plane[LH_VAR_THETA_I]) + top;
+        const FT* re_top = static_cast<const FT*>(in->plane[LH_VAR_RHOE_INT]) + top;
+        launch_atmos_flux<FT>(P, make_atmos_params<FT>(c), c->cfg.ncols, true, any_percol(c), vl_top, ti_top, re_top,
+                              static_cast<FT*>(c->d_atm_flux[0]), static_cast<FT*>(c->d_atm_flux[1]), c->stream);
+        P.bc_kind[LH_FACE_TOP][LH_COMP_ENERGY] = P.bc_kind[LH_FACE_TOP][LH_COMP_HYDROLOGY] = LH_BC_FLUX;
+        P.bc_pc[LH_FACE_TOP][LH_COMP_ENERGY] = static_cast<const FT*>(c->d_atm_flux[0]);
+        P.bc_pc[LH_FACE_TOP][LH_COMP_HYDROLOGY] = static_cast<const FT*>(c->d_atm_flux[1]);
+    }
     // the state theta_i is read from: Ya (HEAT), Y (tendency), the step's base state (fused stages)
     const lh_state* ti_src = c->cfg.model == LH_MODEL_HEAT ? aux : (tend ? in : base);
     const bool noice = c->tune.zero != 0 && ti_src && (ti_src->zero_mask & ti_bit);
@@ -482,6 +538,7 @@ void state_free(lh_ctx* c, lh_state* s) {
 // LH_TUNE=persist=0: never (fused-stage launches), persist=2: always.
 bool use_column_stepper(const lh_ctx* c, int64_t nsteps) {
     if (c->tune.persist == 0 || c->cfg.nlev > 1024) return false;
+    if (c->hp.atmos_on) return false; // the surface fluxes are re-evaluated before every stage launch
     if (c->tune.persist == 2) return true;
     const int64_t threads = c->cfg.ncols * int64_t((c->cfg.nlev + 63) / 64 * 64);
     if (threads <= (int64_t(1) << 20)) return true;
@@ -832,6 +889,10 @@ int lh_destroy(lh_ctx* c) {
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_dt) (void)hipFree(c->d_dt);
+    for (int k = 0; k < 3; ++k)
+        if (c->d_atm_pc[k]) (void)hipFree(c->d_atm_pc[k]);
+    for (int k = 0; k < 2; ++k)
+        if (c->d_atm_flux[k]) (void)hipFree(c->d_atm_flux[k]);
     if (c->d_math_tab) (void)hipFree(c->d_math_tab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -888,6 +949,90 @@ int lh_set_bc(lh_ctx* c, int32_t face, int32_t comp, int32_t kind, double value,
     c->hp.bc_value[face][comp] = value;
     (void)hipSetDevice(c->device);
     return upload_percol(c, &c->d_bc_pc[face][comp], percol);
+}
+
+int lh_set_atmos_forcing(lh_ctx* c, const lh_atmos_forcing* f, const double* percol) {
+    if (!c) return LH_EINVAL;
+    (void)hipSetDevice(c->device);
+    if (!f) { // back to the component boundary conditions of lh_set_bc
+        c->hp.atmos_on = false;
+        for (int k = 0; k < 3; ++k) {
+            int rc = upload_percol(c, &c->d_atm_pc[k], nullptr);
+            if (rc) return rc;
+        }
+        return LH_OK;
+    }
+    if (c->cfg.model != LH_MODEL_COUPLED)
+        return fail(c, LH_EMODEL, "PrescribedAtmosForcing needs SoilEnergyModel + SoilHydrologyModel (no method for this model)");
+    if (!(f->z_atm > 0) || !(f->z_0m > 0) || !(f->z_0s > 0) || !(f->rho_a_sfc > 0) || !(f->theta_scale > 0) ||
+        !(f->R_v > 0) || !(f->von_karman > 0) || !(f->T_triple > 0))
+        return fail(c, LH_EINVAL, "lh_set_atmos_forcing: z_atm, z_0m, z_0s, rho_a_sfc, theta_scale, R_v, von_karman, T_triple must be > 0");
+    for (int k = 0; k < 2; ++k)
+        if (!c->d_atm_flux[k]) LH_HIP(c, hipMalloc(&c->d_atm_flux[k], size_t(c->cfg.ncols) * c->esize));
+    for (int k = 0; k < 3; ++k) {
+        int rc = upload_percol(c, &c->d_atm_pc[k], percol ? percol + size_t(k) * size_t(c->cfg.ncols) : nullptr);
+        if (rc) return rc;
+    }
+    c->hp.atmos = *f;
+    c->hp.atmos_on = true;
+    return LH_OK;
+}
+
+int lh_atmos_surface_fluxes(lh_ctx* c, int64_t n, const double* vl, const double* ti, const double* T,
+                            double* heat, double* water) {
+    if (!c || !vl || !ti || !T || !heat || !water) return fail(c, LH_EINVAL, "lh_atmos_surface_fluxes: NULL argument");
+    if (n < 0) return fail(c, LH_EINVAL, "lh_atmos_surface_fluxes: n < 0");
+    if (!c->hp.atmos_on) return fail(c, LH_EMODEL, "no PrescribedAtmosForcing is set on this model (lh_set_atmos_forcing)");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    if (n == 0) return LH_OK;
+    (void)hipSetDevice(c->device);
+    const size_t es = c->esize;
+    double* d_in = nullptr;   // 3 n doubles in, converted to FT; 2 n FT out
+    char* d_ft = nullptr;
+    LH_HIP(c, hipMalloc(&d_in, size_t(n) * 3 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_ft, size_t(n) * 5 * es);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(c, LH_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    auto cleanup = [&]() {
+        (void)hipFree(d_in);
+        (void)hipFree(d_ft);
+    };
+    const double* src[3] = {vl, ti, T};
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(d_in + size_t(k) * n, src[k], size_t(n) * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    std::vector<char> out(size_t(n) * 2 * es);
+    if (e == hipSuccess) {
+        if (c->cfg.dtype == LH_F64) {
+            double* f = reinterpret_cast<double*>(d_ft);
+            launch_convert<double>(f, d_in, 3 * n, c->stream);
+            launch_atmos_flux<double>(make_params<double>(c), make_atmos_params<double>(c), n, false, false, f, f + n, f + 2 * n,
+                                      f + 3 * n, f + 4 * n, c->stream);
+        } else {
+            float* f = reinterpret_cast<float*>(d_ft);
+            launch_convert<float>(f, d_in, 3 * n, c->stream);
+            launch_atmos_flux<float>(make_params<float>(c), make_atmos_params<float>(c), n, false, false, f, f + n, f + 2 * n,
+                                     f + 3 * n, f + 4 * n, c->stream);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_ft + size_t(n) * 3 * es, size_t(n) * 2 * es, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, LH_ENODEVICE, "lh_atmos_surface_fluxes failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    for (int64_t i = 0; i < n; ++i) {
+        if (c->cfg.dtype == LH_F64) {
+            heat[i] = reinterpret_cast<const double*>(out.data())[i];
+            water[i] = reinterpret_cast<const double*>(out.data())[n + i];
+        } else {
+            heat[i] = reinterpret_cast<const float*>(out.data())[i];
+            water[i] = reinterpret_cast<const float*>(out.data())[n + i];
+        }
+    }
+    return LH_OK;
 }
 
 int lh_set_bottom_sign_consistent(lh_ctx* c, int32_t flag) {

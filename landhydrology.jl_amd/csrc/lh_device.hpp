@@ -77,6 +77,20 @@ struct DevParams {
     int32_t xcd_remap;      // workgroup -> column-block map that gives each XCD one contiguous column range
 };
 
+// PrescribedAtmosForcing{FT} (boundary_conditions.jl:119-132) plus every constant
+// compute_turbulent_surface_fluxes (:553-620) reads, rounded to FT (lh_atmos.hpp)
+template <typename FT>
+struct AtmosParams {
+    FT u_atm, theta_atm, z_atm, theta_scale, rho_a_sfc, q_atm; // PrescribedAtmosForcing{FT}
+    FT z_0m, z_0s;                                             // SoilParams.z_0m, z_0s
+    FT R_v, R_d, grav, cp_d, cp_v, T_triple, press_triple, von_karman;
+    FT cp_l, T_0, rho_liq;   // from the earth parameters of the context
+    double cp_v_d, LH_v0_d;  // FT(cp_v (T - T_ref) + LH_v0): formed in Float64, rounded once (:614-615)
+    const FT* pc_u;          // per-column u_atm / theta_atm / q_atm or nullptr
+    const FT* pc_theta;
+    const FT* pc_q;
+};
+
 // one FieldVector on the device: up to four planes [nlev][stride]
 template <typename FT>
 struct Planes {

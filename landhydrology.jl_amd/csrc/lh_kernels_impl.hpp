@@ -12,6 +12,7 @@
 #pragma once
 #include "lh_closures.hpp"
 #include "lh_launch.hpp"
+#include "lh_atmos.hpp"
 #include <type_traits>
 
 namespace lh {
@@ -1254,6 +1255,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
                                           hipStream_t);                                               \
     template void launch_stream_probe<FT>(int64_t, int64_t, int, int, const Planes<FT>&, int,         \
                                           const Planes<FT>&, int, bool, hipStream_t);                 \
+    template void launch_atmos_flux<FT>(const DevParams<FT>&, const AtmosParams<FT>&, int64_t, bool,  \
+                                        bool, const FT*, const FT*, const FT*, FT*, FT*, hipStream_t); \
     template void launch_fill<FT>(FT*, int64_t, FT, hipStream_t);                                     \
     template void launch_convert<FT>(FT*, const double*, int64_t, hipStream_t);
 

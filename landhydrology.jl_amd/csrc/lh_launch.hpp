@@ -50,6 +50,10 @@ void launch_strided_copy(FT* plane, int64_t stride, FT* user, int64_t ls, int64_
 template <typename FT>
 void launch_stream_probe(int64_t ncols, int64_t stride, int nlev, int xcd_remap, const Planes<FT>& in, int nr,
                          const Planes<FT>& out, int nw, bool nt, hipStream_t s);
+// compute_turbulent_surface_fluxes for n top-cell states (lh_atmos.hpp)
+template <typename FT>
+void launch_atmos_flux(const DevParams<FT>& P, const AtmosParams<FT>& A, int64_t n, bool from_state, bool percol,
+                       const FT* vl, const FT* ti, const FT* third, FT* out_heat, FT* out_water, hipStream_t s);
 template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s);
 template <typename FT>

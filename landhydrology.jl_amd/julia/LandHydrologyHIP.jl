@@ -30,11 +30,13 @@ using LandHydrology
 using LandHydrology.SoilInterface
 using LandHydrology.SoilInterface: SoilModel, SoilEnergyModel, SoilHydrologyModel,
     PrescribedTemperatureModel, PrescribedHydrologyModel, NoBC, VerticalFlux, Dirichlet,
-    FreeDrainage, SoilComponentBC
+    FreeDrainage, SoilComponentBC, PrescribedAtmosForcing
 using LandHydrology.SoilInterface.SoilWaterParameterizations:
     NoEffect, TemperatureDependentViscosity, IceImpedance
-using CLIMAParameters.Planet: ρ_cloud_liq, ρ_cloud_ice, cp_l, cp_i, T_0, LH_f0
+using CLIMAParameters.Planet: ρ_cloud_liq, ρ_cloud_ice, cp_l, cp_i, T_0, LH_f0, R_v, R_d, grav, cp_d,
+    cp_v, LH_v0, T_triple, press_triple
 using CLIMAParameters.Atmos.Microphysics: K_therm
+using CLIMAParameters.SubgridScale: von_karman_const
 import LandHydrology.SoilInterface: make_rhs
 
 export HIPBackend, ColumnEnsemble, upload, download, device_rhs!, step_ssprk33!, stable_dt,
@@ -64,6 +66,12 @@ struct lh_soil_params
 end
 struct lh_vg_params
     n::Float64; alpha::Float64; theta_r::Float64; Ksat::Float64
+end
+struct lh_atmos_forcing          # PrescribedAtmosForcing + z_0m, z_0s + the constants of :553-620
+    u_atm::Float64; theta_atm::Float64; z_atm::Float64; theta_scale::Float64; rho_a_sfc::Float64
+    q_atm::Float64; z_0m::Float64; z_0s::Float64
+    R_v::Float64; R_d::Float64; grav::Float64; cp_d::Float64; cp_v::Float64; LH_v0::Float64
+    T_triple::Float64; press_triple::Float64; von_karman::Float64
 end
 
 const LH_BC_NONE, LH_BC_FLUX, LH_BC_DIRICHLET, LH_BC_FREE_DRAINAGE = Int32(0), Int32(1), Int32(2), Int32(3)
@@ -158,7 +166,19 @@ end
 function set_bcs!(ens::ColumnEnsemble, t)
     bcs = ens.model.boundary_conditions
     for (face, fbc) in ((LH_FACE_BOTTOM, bcs.bottom), (LH_FACE_TOP, bcs.top))
-        fbc isa SoilComponentBC || error("PrescribedAtmosForcing is outside the accelerated path")
+        if fbc isa PrescribedAtmosForcing
+            # boundary_conditions.jl:523-528: only valid at the top (SoilColumnBC's type parameters
+            # already exclude the bottom).  The surface fluxes are computed on the device from the
+            # top cell before every tendency evaluation (lh_set_atmos_forcing, csrc/lh_atmos.hpp).
+            face == LH_FACE_TOP || error("Prescribed atmosphere-driven boundary conditions are only valid at the top of the soil column.")
+            ps, sp = ens.model.earth_param_set, ens.model.soil_param_set
+            f = Ref(lh_atmos_forcing(fbc.u_atm, fbc.θ_atm, fbc.z_atm, fbc.θ_scale, fbc.ρ_a_sfc, fbc.q_atm,
+                                     sp.z_0m, sp.z_0s, R_v(ps), R_d(ps), grav(ps), cp_d(ps), cp_v(ps),
+                                     LH_v0(ps), T_triple(ps), press_triple(ps), von_karman_const(ps)))
+            check(ens.ctx, ccall((:lh_set_atmos_forcing, lib), Cint,
+                                 (Ptr{Cvoid}, Ptr{lh_atmos_forcing}, Ptr{Float64}), ens.ctx, f, C_NULL))
+            continue
+        end
         for (comp, bc) in ((LH_COMP_ENERGY, fbc.energy), (LH_COMP_HYDROLOGY, fbc.hydrology))
             check(ens.ctx, ccall((:lh_set_bc, lib), Cint,
                                  (Ptr{Cvoid}, Int32, Int32, Int32, Float64, Ptr{Float64}),
@@ -268,10 +288,24 @@ end
 bc_stage_values(ens::ColumnEnsemble, ts) = begin
     bcs = ens.model.boundary_conditions
     vals = Array{Float64}(undef, 2, 2)                 # (component, face): C order [face][component]
-    for (f, fbc) in enumerate((bcs.bottom, bcs.top)), (c, bc) in enumerate((fbc.energy, fbc.hydrology))
-        vals[c, f] = bc_value(bc, ts)
+    fill!(vals, 0.0)
+    for (f, fbc) in enumerate((bcs.bottom, bcs.top))
+        fbc isa SoilComponentBC || continue            # a prescribed atmosphere has no stage values
+        for (c, bc) in enumerate((fbc.energy, fbc.hydrology))
+            vals[c, f] = bc_value(bc, ts)
+        end
     end
     vals
+end
+
+"compute_turbulent_surface_fluxes.(energy, hydrology, model, ϑ_l, θ_i, T) on the device (boundary_conditions.jl:553-620)"
+function turbulent_surface_fluxes(ens::ColumnEnsemble, ϑ_l::Vector{Float64}, θ_i::Vector{Float64}, T::Vector{Float64})
+    n = length(ϑ_l)
+    heat, water = Vector{Float64}(undef, n), Vector{Float64}(undef, n)
+    check(ens.ctx, ccall((:lh_atmos_surface_fluxes, lib), Cint,
+                         (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                         ens.ctx, n, ϑ_l, θ_i, T, heat, water))
+    return heat, water
 end
 
 """

@@ -92,6 +92,18 @@ class EarthParameterSet:
     T_0: float = 273.16
     LH_f0: float = 2.8344e6 - 2.5008e6   # LH_s0 - LH_v0
     K_therm: float = 2.4e-2
+    # read by the prescribed-atmosphere BC only (boundary_conditions.jl:553-620 and the
+    # SurfaceFluxes / Thermodynamics calls it makes): Planet.R_v, R_d, grav, cp_d, cp_v, LH_v0,
+    # T_triple, press_triple; SubgridScale.von_karman_const
+    R_v: float = 8.3144598 / 18.01528e-3
+    R_d: float = 8.3144598 / 28.97e-3
+    grav: float = 9.81
+    cp_d: float = (8.3144598 / 28.97e-3) / (2.0 / 7.0)
+    cp_v: float = 1859.0
+    LH_v0: float = 2.5008e6
+    T_triple: float = 273.16
+    press_triple: float = 611.657
+    von_karman_const: float = 0.4
 
 
 _SOIL_DEFAULTS = dict(nu=0.43, S_s=1e-3, nu_ss_gravel=0.0, nu_ss_om=0.0, nu_ss_quartz=0.41,
@@ -255,12 +267,32 @@ class SoilComponentBC:
 
 
 class PrescribedAtmosForcing:
-    """boundary_conditions.jl:119-132 -- outside the hot path."""
+    """PrescribedAtmosForcing{FT}(; u_atm, θ_atm, z_atm, θ_scale, ρ_a_sfc, q_atm)
+    (boundary_conditions.jl:119-132): the atmospheric state that drives the TOP face of a coupled
+    water + heat soil model through Monin-Obukhov surface fluxes (:553-620), evaluated on the
+    device from the top cell's state.  `u_atm`, `θ_atm`, `q_atm` may be arrays of ncolumns values
+    (build extension).  Parity beyond the reference's equilibrium invariant is unpinned: the
+    SurfaceFluxes / Thermodynamics formulas are restated from their published forms."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError(
-            "PrescribedAtmosForcing (Monin-Obukhov surface fluxes) is out of scope of the "
-            "accelerated path; see DESIGN.md")
+    _FIELDS = ("u_atm", "theta_atm", "z_atm", "theta_scale", "rho_a_sfc", "q_atm")
+    _ALIASES = {"θ_atm": "theta_atm", "θ_scale": "theta_scale", "ρ_a_sfc": "rho_a_sfc"}
+
+    def __init__(self, FT=Float64, **kw):
+        self.FT = np.dtype(FT).type
+        vals = {}
+        for k, v in kw.items():
+            k = self._ALIASES.get(k, k)
+            if k not in self._FIELDS:
+                raise TypeError(f"PrescribedAtmosForcing has no field {k!r}")
+            vals[k] = v
+        missing = [k for k in self._FIELDS if k not in vals]
+        if missing:                                  # Base.@kwdef without defaults: UndefKeywordError
+            raise TypeError(f"PrescribedAtmosForcing: keyword argument(s) {missing} not assigned")
+        self.__dict__.update(vals)
+
+    θ_atm = property(lambda s: s.theta_atm)
+    θ_scale = property(lambda s: s.theta_scale)
+    ρ_a_sfc = property(lambda s: s.rho_a_sfc)
 
 
 class SoilColumnBC:
@@ -269,8 +301,11 @@ class SoilColumnBC:
     def __init__(self, *, top=None, bottom=None):
         self.top = top if top is not None else SoilComponentBC()
         self.bottom = bottom if bottom is not None else SoilComponentBC()
-        if not isinstance(self.bottom, SoilComponentBC) or not isinstance(self.top, SoilComponentBC):
-            raise TypeError("top/bottom must be SoilComponentBC")
+        # SoilColumnBC{TBC <: Union{SoilComponentBC, PrescribedAtmosForcing}, BBC <: SoilComponentBC}
+        if not isinstance(self.bottom, SoilComponentBC):
+            raise TypeError("bottom must be a SoilComponentBC (a prescribed atmosphere is only valid at the top)")
+        if not isinstance(self.top, (SoilComponentBC, PrescribedAtmosForcing)):
+            raise TypeError("top must be a SoilComponentBC or a PrescribedAtmosForcing")
 
 
 _BC_KIND = {NoBC: F.LH_BC_NONE, VerticalFlux: F.LH_BC_FLUX, Dirichlet: F.LH_BC_DIRICHLET,
@@ -449,6 +484,8 @@ class _Backend:
         out = {}
         for face, tag in ((F.LH_FACE_BOTTOM, "bottom"), (F.LH_FACE_TOP, "top")):
             fbc = getattr(model.boundary_conditions, tag)
+            if isinstance(fbc, PrescribedAtmosForcing):      # set through lh_set_atmos_forcing
+                continue
             for comp, cname in ((F.LH_COMP_ENERGY, "energy"), (F.LH_COMP_HYDROLOGY, "hydrology")):
                 bc = getattr(fbc, cname)
                 kind = _BC_KIND.get(type(bc))
@@ -462,11 +499,46 @@ class _Backend:
                 out[(face, comp)] = (kind, val)
         return out
 
+    def set_atmos(self, model):
+        """lh_set_atmos_forcing from SoilColumnBC.top (or its removal)."""
+        L = F.lib()
+        d = model.domain
+        top = model.boundary_conditions.top
+        if not isinstance(top, PrescribedAtmosForcing):
+            if getattr(self, "_atmos_set", False):
+                F.check(L.lh_set_atmos_forcing(self.ctx, None, None), self.ctx)
+                self._atmos_set = False
+            return
+        ep, sp = model.earth_param_set, model.soil_param_set
+        scal, percol = {}, np.zeros((3, d.ncolumns))
+        any_pc = False
+        for k, name in enumerate(("u_atm", "theta_atm", "q_atm")):
+            a = np.asarray(getattr(top, name), dtype=np.float64)
+            if a.ndim == 0:
+                scal[name] = float(a)
+                percol[k] = float(a)
+            else:
+                if a.shape != (d.ncolumns,):
+                    raise ValueError(f"{name}: expected {d.ncolumns} per-column values")
+                scal[name] = float(a[0])
+                percol[k] = a
+                any_pc = True
+        f = F.lh_atmos_forcing(scal["u_atm"], scal["theta_atm"], float(top.z_atm), float(top.theta_scale),
+                               float(top.rho_a_sfc), scal["q_atm"], float(sp.z_0m), float(sp.z_0s),
+                               ep.R_v, ep.R_d, ep.grav, ep.cp_d, ep.cp_v, ep.LH_v0, ep.T_triple,
+                               ep.press_triple, ep.von_karman_const)
+        percol = np.ascontiguousarray(percol)
+        F.check(L.lh_set_atmos_forcing(self.ctx, C.byref(f),
+                                       percol.ctypes.data_as(C.POINTER(C.c_double)) if any_pc else None),
+                self.ctx)
+        self._atmos_set = True
+
     def set_bcs(self, model, t):
         if model.boundary_conditions is None:
             return
         L = F.lib()
         d = model.domain
+        self.set_atmos(model)
         for (face, comp), (kind, val) in self.bc_values(model, t).items():
             a = np.asarray(val, dtype=np.float64)
             if a.ndim == 0:
@@ -702,6 +774,44 @@ def make_rhs(model: SoilModel):
         return dY
 
     return rhs
+
+
+def compute_turbulent_surface_fluxes(energy, hydrology, model: SoilModel, vartheta_l, theta_i, T):
+    """compute_turbulent_surface_fluxes(energy, hydrology, model, ϑ_l, θ_i, T)
+    (boundary_conditions.jl:553-620) -> (heat_flux, Ẽ): the surface heat flux and water volume
+    flux the prescribed atmosphere of `model.boundary_conditions.top` drives for a top-cell state
+    (scalars or arrays), evaluated on the device (lh_atmos_surface_fluxes).  Only
+    SoilEnergyModel + SoilHydrologyModel has a method (test_prescribed_atmos_bc.jl:161-183)."""
+    if not (isinstance(energy, SoilEnergyModel) and isinstance(hydrology, SoilHydrologyModel)):
+        raise TypeError("no method compute_turbulent_surface_fluxes for "
+                        f"({type(energy).__name__}, {type(hydrology).__name__})")
+    be = model._backend()
+    be.set_bcs(model, 0.0)
+    vl, ti, T = np.broadcast_arrays(*(np.asarray(a, dtype=np.float64) for a in (vartheta_l, theta_i, T)))
+    shape = vl.shape
+    vl, ti, T = (np.ascontiguousarray(a.reshape(-1)) for a in (vl, ti, T))
+    heat, water = np.empty_like(vl), np.empty_like(vl)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    F.check(F.lib().lh_atmos_surface_fluxes(be.ctx, vl.size, dp(vl), dp(ti), dp(T), dp(heat), dp(water)), be.ctx)
+    FT = model.FT
+    if shape == ():
+        return FT(heat[0]), FT(water[0])
+    return heat.reshape(shape).astype(FT), water.reshape(shape).astype(FT)
+
+
+def boundary_fluxes(X, bc, face, model: SoilModel, cs=None, t=0.0):
+    """boundary_fluxes(X, bc::PrescribedAtmosForcing, face, model, cs, t)
+    (boundary_conditions.jl:516-533) for a host-side X = (ϑ_l, θ_i, T) of the cell next to the
+    face: the named pair (fρe_int, fϑ_l).  Component boundary conditions are evaluated inside the
+    tendency kernel and have no host form here."""
+    if not isinstance(bc, PrescribedAtmosForcing):
+        raise NotImplementedError("component boundary conditions are evaluated on the device by rhs!")
+    if face not in ("top", ":top"):
+        raise RuntimeError("Prescribed atmosphere-driven boundary conditions are only valid at the "
+                           "top of the soil column.")            # :523-528
+    vl, ti, T = X
+    h, w = compute_turbulent_surface_fluxes(model.energy_model, model.hydrology_model, model, vl, ti, T)
+    return {"fρe_int": h, "fϑ_l": w}
 
 
 def stable_dt(model: SoilModel, Y: "FieldVector", Ya=None, courant: float = 0.5) -> float:

@@ -22,6 +22,8 @@
 #define FT_EXP exp
 #define FT_SQRT sqrt
 #define FT_FABS fabs
+#define FT_LOG log
+#define FT_ATAN atan
 #include "lh_oracle_impl.inc"
 #undef FT
 #undef SFX
@@ -30,6 +32,8 @@
 #undef FT_EXP
 #undef FT_SQRT
 #undef FT_FABS
+#undef FT_LOG
+#undef FT_ATAN
 
 /* ---- Float32 ---- */
 #define FT float
@@ -39,6 +43,8 @@
 #define FT_EXP expf
 #define FT_SQRT sqrtf
 #define FT_FABS fabsf
+#define FT_LOG logf
+#define FT_ATAN atanf
 #include "lh_oracle_impl.inc"
 #undef FT
 #undef SFX
@@ -47,6 +53,8 @@
 #undef FT_EXP
 #undef FT_SQRT
 #undef FT_FABS
+#undef FT_LOG
+#undef FT_ATAN
 
 int lho_openmp_max_threads(void) {
 #ifdef _OPENMP

@@ -33,6 +33,7 @@ extern "C" {
 
 enum { LHO_MODEL_RICHARDS = 0, LHO_MODEL_HEAT = 1, LHO_MODEL_COUPLED = 2 };
 enum { LHO_BC_NONE = 0, LHO_BC_FLUX = 1, LHO_BC_DIRICHLET = 2, LHO_BC_FREE_DRAINAGE = 3 };
+/* (PrescribedAtmosForcing is a property of the whole top face: lho_model.atmos_on) */
 enum { LHO_FACE_BOTTOM = 0, LHO_FACE_TOP = 1 };
 enum { LHO_COMP_ENERGY = 0, LHO_COMP_HYDROLOGY = 1 };
 enum { LHO_FACTOR_NONE = 0, LHO_FACTOR_ON = 1 };
@@ -61,6 +62,20 @@ typedef struct {
     double gamma, T_ref, Omega;
 } lho_cond_factors;
 
+/* PrescribedAtmosForcing{FT} (src/SoilModel/boundary_conditions.jl:119-132), the roughness
+ * lengths it reads from SoilParams (parameters.jl:38-41), and the CLIMAParameters constants
+ * compute_turbulent_surface_fluxes (:553-620) and the two un-vendored packages it calls
+ * (SurfaceFluxes 0.1, Thermodynamics 0.5) consume.  PARITY UNPINNED beyond the reference's
+ * equilibrium invariant (test_prescribed_atmos_bc.jl:75-79): the Monin-Obukhov and saturation
+ * formulas are restated from their published forms, not from sources under the reference tree
+ * (SURVEY.md Appendix B). */
+typedef struct {
+    double u_atm, theta_atm, z_atm, theta_scale, rho_a_sfc, q_atm; /* the six fields, :119-132 */
+    double z_0m, z_0s;                                             /* SoilParams */
+    double R_v, R_d, grav, cp_d, cp_v, LH_v0, T_triple, press_triple; /* CLIMAParameters.Planet */
+    double von_karman;                                             /* SubgridScale.von_karman_const */
+} lho_atmos_forcing;
+
 typedef struct {
     int32_t kind; /* LHO_BC_* */
     int32_t pad_;
@@ -80,13 +95,17 @@ typedef struct {
      * gravity term keeps the top-face sign at the bottom); 1 = physically
      * consistent sign. */
     int32_t consistent_bottom_sign;
-    int32_t pad_;
+    /* 1: the top face is a PrescribedAtmosForcing (bc[TOP][*] are then ignored); only the
+     * coupled model has a method (boundary_conditions.jl:553-560) */
+    int32_t atmos_on;
+    lho_atmos_forcing atmos;
 } lho_model;
 
 /* Optional per-column overrides (NULL = use the scalar in lho_model). */
 typedef struct {
     const double *vg_n, *vg_alpha, *vg_theta_r, *vg_Ksat, *nu, *S_s;
     const double *bc_value[2][2]; /* [face][component], per column */
+    const double *atm_u, *atm_theta, *atm_q; /* per-column u_atm, theta_atm, q_atm */
 } lho_percol;
 
 /* ---- grid (domain.jl:58-69; coupled.jl:198) -------------------------- */
@@ -146,6 +165,15 @@ float lho_k_solid_f32(float nu_om, float nu_q, float k_q, float k_min, float k_o
 float lho_ksat_frozen_f32(float k_solid, float porosity, float k_ice);
 float lho_ksat_unfrozen_f32(float k_solid, float porosity, float k_l);
 float lho_k_dry_f32(const lho_earth_params*, const lho_soil_params*);
+
+/* compute_turbulent_surface_fluxes(energy, hydrology, model, vartheta_l, theta_i, T)
+ * (boundary_conditions.jl:553-620) for the top-cell state of one column: the heat flux and the
+ * water volume flux through the surface (positive upward).  Returns 0, 1 when the
+ * Monin-Obukhov system has no root (bulk Richardson number past the critical one: fluxes NaN). */
+int lho_turbulent_surface_fluxes_f64(const lho_model*, double vl, double ti, double T,
+                                     double* heat_flux, double* water_flux);
+int lho_turbulent_surface_fluxes_f32(const lho_model*, float vl, float ti, float T,
+                                     float* heat_flux, float* water_flux);
 
 /* ---- batched tendency: rhs!(dY, Y, Ya, t) -----------------------------
  * Arrays are addressed as a[c*col_stride + i*lev_stride] (element strides).

@@ -47,11 +47,19 @@ class BC(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("value", C.c_double)]
 
 
+class AtmosForcing(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("u_atm", "theta_atm", "z_atm", "theta_scale", "rho_a_sfc", "q_atm", "z_0m", "z_0s",
+                 "R_v", "R_d", "grav", "cp_d", "cp_v", "LH_v0", "T_triple", "press_triple",
+                 "von_karman")]
+
+
 class Model(C.Structure):
     _fields_ = [("model", C.c_int32), ("nlev", C.c_int32), ("zmin", C.c_double),
                 ("zmax", C.c_double), ("earth", EarthParams), ("soil", SoilParams),
                 ("vg", VGParams), ("cf", CondFactors), ("bc", (BC * 2) * 2),
-                ("consistent_bottom_sign", C.c_int32), ("pad_", C.c_int32)]
+                ("consistent_bottom_sign", C.c_int32), ("atmos_on", C.c_int32),
+                ("atmos", AtmosForcing)]
 
 
 _DP = C.POINTER(C.c_double)
@@ -59,7 +67,8 @@ _DP = C.POINTER(C.c_double)
 
 class PerCol(C.Structure):
     _fields_ = [("vg_n", _DP), ("vg_alpha", _DP), ("vg_theta_r", _DP), ("vg_Ksat", _DP),
-                ("nu", _DP), ("S_s", _DP), ("bc_value", (_DP * 2) * 2)]
+                ("nu", _DP), ("S_s", _DP), ("bc_value", (_DP * 2) * 2),
+                ("atm_u", _DP), ("atm_theta", _DP), ("atm_q", _DP)]
 
 
 def build(force: bool = False) -> str:
@@ -124,6 +133,7 @@ def _declare(L):
         sig("lho_ssprk33", C.c_int, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double, C.c_double,
                                      i64, _DP, C.c_int])
         sig("lho_stable_dt", C.c_double, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double])
+        sig("lho_turbulent_surface_fluxes", C.c_int, [mp, ft, ft, ft, P, P])
     L.lho_openmp_max_threads.restype = C.c_int
 
 
@@ -169,11 +179,17 @@ def c_model(om) -> Model:
             m.bc[f][k].kind = kind
             m.bc[f][k].value = val
     m.consistent_bottom_sign = int(om.consistent_bottom_sign)
+    atm = getattr(om, "atmos", None)
+    m.atmos_on = int(atm is not None)
+    if atm is not None:
+        vals = {n: getattr(atm, n) for n, _ in AtmosForcing._fields_ if hasattr(atm, n)}
+        vals["z_0m"], vals["z_0s"] = om.soil.z_0m, om.soil.z_0s      # SoilParams roughness lengths
+        m.atmos = AtmosForcing(**vals)
     return m
 
 
 def c_percol(om):
-    if not om.percol and not om.percol_bc:
+    if not om.percol and not om.percol_bc and not getattr(om, "percol_atmos", None):
         return None, []
     keep = []
     pc = PerCol()
@@ -186,6 +202,11 @@ def c_percol(om):
         a = np.ascontiguousarray(v, dtype=np.float64)
         keep.append(a)
         pc.bc_value[f][k] = a.ctypes.data_as(_DP)
+    for name, v in (getattr(om, "percol_atmos", None) or {}).items():     # u_atm / theta_atm / q_atm
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        keep.append(a)
+        setattr(pc, {"u_atm": "atm_u", "theta_atm": "atm_theta", "q_atm": "atm_q"}[name],
+                a.ctypes.data_as(_DP))
     return pc, keep
 
 
@@ -301,6 +322,22 @@ def stable_dt(om, vl, ti, rhoe=None, courant=0.5, T_aux=None):
                                    _ptr(T_aux, ft), ls, cs, float(courant))
     del keep
     return r
+
+
+def turbulent_surface_fluxes(om, vl, ti, T, dtype=np.float64):
+    """compute_turbulent_surface_fluxes (boundary_conditions.jl:553-620) for arrays of top-cell
+    states -> (heat_flux, water_flux, status) arrays; status 1 = no Monin-Obukhov root."""
+    ft = _ft(dtype)
+    m = c_model(om)
+    vl, ti, T = (np.atleast_1d(np.asarray(a, dtype=dtype)) for a in (vl, ti, T))
+    h, w = np.empty_like(vl), np.empty_like(vl)
+    st = np.zeros(vl.shape, dtype=np.int32)
+    f = fn("lho_turbulent_surface_fluxes", dtype)
+    hh, ww = ft(), ft()
+    for i in range(vl.size):
+        st.flat[i] = f(C.byref(m), ft(vl.flat[i]), ft(ti.flat[i]), ft(T.flat[i]), C.byref(hh), C.byref(ww))
+        h.flat[i], w.flat[i] = hh.value, ww.value
+    return h, w, st
 
 
 def max_threads() -> int:

@@ -125,3 +125,5 @@ class CaseModel:
     percol_bc: dict = field(default_factory=dict)
     # PrescribedAtmosForcing at the top face (then bc has no top entries), or None
     atmos: AtmosForcing = None
+    # per-column overrides of u_atm / theta_atm / q_atm: name -> float64 array [ncols]
+    percol_atmos: dict = field(default_factory=dict)

@@ -316,6 +316,18 @@ class GpuModel:
             F.check(L.lh_set_percol_param(ctx, F.LH_PC[key], a.ctypes.data_as(
                 C.POINTER(C.c_double))), ctx)
         self.set_bcs(om)
+        if getattr(om, "atmos", None) is not None:      # PrescribedAtmosForcing at the top face
+            a = om.atmos
+            f = F.lh_atmos_forcing(a.u_atm, a.theta_atm, a.z_atm, a.theta_scale, a.rho_a_sfc, a.q_atm,
+                                   om.soil.z_0m, om.soil.z_0s, a.R_v, a.R_d, a.grav, a.cp_d, a.cp_v,
+                                   a.LH_v0, a.T_triple, a.press_triple, a.von_karman)
+            pc = None
+            if om.percol_atmos:
+                pc = np.ascontiguousarray(np.stack([
+                    np.asarray(om.percol_atmos.get(k, np.full(case.ncols, getattr(a, k))), dtype=np.float64)
+                    for k in ("u_atm", "theta_atm", "q_atm")]))
+            F.check(L.lh_set_atmos_forcing(ctx, C.byref(f),
+                                           pc.ctypes.data_as(C.POINTER(C.c_double)) if pc is not None else None), ctx)
         F.check(L.lh_set_bottom_sign_consistent(ctx, int(om.consistent_bottom_sign)), ctx)
         if math_mode is not None:
             F.check(L.lh_set_math_mode(ctx, math_mode), ctx)

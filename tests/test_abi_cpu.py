@@ -98,8 +98,14 @@ def test_host_mirror_domain_and_errors(pkg):
     zc, zf = pkg.make_function_space(pkg.Column(np.float64, zlim=(-2.0, 0.0), nelements=20))
     want = np.array([(-195 + 10 * i) / 100 for i in range(20)])
     assert np.allclose(zc, want, rtol=0, atol=4.5e-16)           # coupled.jl:198
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                                # Base.@kwdef: every field is required
         pkg.PrescribedAtmosForcing(u_atm=1.0)
+    atm = pkg.PrescribedAtmosForcing(u_atm=0.34, θ_atm=299.0, z_atm=0.05, θ_scale=299.0, ρ_a_sfc=1.17,
+                                     q_atm=0.015)
+    assert atm.θ_atm == 299.0 and atm.rho_a_sfc == 1.17
+    pkg.SoilColumnBC(top=atm, bottom=pkg.SoilComponentBC())
+    with pytest.raises(TypeError):                                # BBC <: SoilComponentBC
+        pkg.SoilColumnBC(top=pkg.SoilComponentBC(), bottom=atm)
 
 
 def test_bench_input_generation_executes_nothing_of_the_oracle():

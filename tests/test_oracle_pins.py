@@ -2,6 +2,7 @@
 the hot path.  The reference is Julia and cannot
 run here; these are its own closed forms, grids and conservation results.
 Citations are file:line under the reference tree."""
+import dataclasses
 import math
 
 import numpy as np
@@ -422,3 +423,73 @@ def test_input_generation_helpers_match_the_oracle():
     assert k_solid == pc.COUPLED_K_SOLID
     assert f("lho_ksat_unfrozen", k_solid, 0.5, 0.57) == pc.COUPLED_KSAT_UNFROZEN
     assert f("lho_ksat_frozen", k_solid, 0.5, 2.29) == pc.COUPLED_KSAT_FROZEN
+
+
+# ------------------------------------------------ K10: prescribed-atmosphere BC (8f-4)
+def _atmos_reference_model(q_atm=None, T_surf=299.0):
+    """test/SoilModel/test_prescribed_atmos_bc.jl:9-57"""
+    atm = M.AtmosForcing(u_atm=0.34, theta_atm=T_surf, z_atm=0.05, theta_scale=T_surf, rho_a_sfc=1.17,
+                         q_atm=0.0 if q_atm is None else q_atm)
+    if q_atm is None:       # q_vap_saturation_generic(param_set, T_surf, rho_a_sfc, Liquid()) (:28)
+        e = M.default_earth()
+        dcp = atm.cp_v - e.cp_l
+        p = atm.press_triple * (T_surf / atm.T_triple) ** (dcp / atm.R_v) * math.exp(
+            (atm.LH_v0 - dcp * e.T_0) / atm.R_v * (1 / atm.T_triple - 1 / T_surf))
+        atm.q_atm = p / (atm.rho_a_sfc * atm.R_v * T_surf)
+    return M.CaseModel(M.MODEL_COUPLED, 10, -0.55, 0.0, soil=M.default_soil(nu=0.55, rho_c_ds=1.0),
+                       vg=M.default_vg(n=1.68, alpha=5.0, Ksat=0.0, theta_r=0.084),
+                       bc={(M.FACE_BOTTOM, M.COMP_ENERGY): (M.BC_FLUX, 0.0),
+                           (M.FACE_BOTTOM, M.COMP_HYDROLOGY): (M.BC_FLUX, 0.0)}, atmos=atm)
+
+
+def test_k10_prescribed_atmosphere_equilibrium_invariant():
+    """test_prescribed_atmos_bc.jl:59-79: saturated soil and saturated air at the same
+    temperature exchange nothing: `sum(parent(dY)) == 0.0`.  The ONLY reference-held answer for
+    this boundary condition (SurfaceFluxes.jl / Thermodynamics.jl are not in the reference tree:
+    everything else about it is parity-unpinned)."""
+    om = _atmos_reference_model()
+    n = 10
+    e, sp = om.earth, om.soil
+    rho_c_s = call("lho_volumetric_heat_capacity", F64, sp.nu, 0.0, sp.rho_c_ds, e)
+    rhoe = call("lho_volumetric_internal_energy", F64, 0.0, rho_c_s, 299.0, e)
+    vl = np.full((1, n), sp.nu)
+    d = O.rhs(om, vl, np.zeros((1, n)), np.full((1, n), rhoe))
+    assert sum(float(np.sum(v)) for v in d.values()) == 0.0
+    assert not any(np.any(v) for v in d.values())
+
+
+def test_k10_surface_flux_properties():
+    """test_prescribed_atmos_bc.jl:81-159 as far as it needs no un-vendored package: oversaturated
+    == saturated (:155), neutral => tstar == 0 => no sensible heat (:148-151), plus the physics
+    any correct evaluation must show (signs, monotonicity in the wind, no root past the critical
+    Richardson number)."""
+    om = _atmos_reference_model()
+    nu = 0.55
+    h, w, st = O.turbulent_surface_fluxes(om, [nu, nu + 1e-3, nu - 1e-3, nu], [0, 0, 0, 0.1],
+                                          [299.0, 299.0, 289.5, 289.5])
+    assert not st.any()
+    assert h[0] == 0.0 and w[0] == 0.0 and (h[0], w[0]) == (h[1], w[1])
+    assert h[2] < 0 and h[3] < 0           # warm air, cold soil: heat flows down (negative z-flux)
+    dry = dataclasses.replace(om, atmos=dataclasses.replace(om.atmos, q_atm=0.005))
+    h2, w2, _ = O.turbulent_surface_fluxes(dry, [0.4], [0.0], [299.0])
+    assert w2[0] > 0 and h2[0] > 0         # dry air over moist soil at equal temperature: evaporation
+    winds = [O.turbulent_surface_fluxes(dataclasses.replace(dry, atmos=dataclasses.replace(dry.atmos, u_atm=u)),
+                                        [0.4], [0.0], [305.0])[1][0] for u in (0.2, 1.0, 5.0)]
+    assert winds[0] < winds[1] < winds[2]  # more wind, more evaporation
+    assert O.turbulent_surface_fluxes(dry, [0.4], [0.0], [250.0])[2][0] == 1       # no root
+    # Float32 runs the same code (the reference itself cannot: min(S, 1.0) promotes to Float64)
+    h32, w32, _ = O.turbulent_surface_fluxes(dry, [0.4], [0.0], [305.0], dtype=F32)
+    h64, w64, _ = O.turbulent_surface_fluxes(dry, [0.4], [0.0], [305.0])
+    assert h32[0] == pytest.approx(h64[0], rel=1e-4) and w32[0] == pytest.approx(w64[0], rel=1e-4)
+
+
+def test_k10_error_paths():
+    """boundary_conditions.jl:553-560: compute_turbulent_surface_fluxes has a method for
+    SoilEnergyModel + SoilHydrologyModel only (test_prescribed_atmos_bc.jl:161-183)."""
+    om = _atmos_reference_model()
+    n = 10
+    vl, ti = np.full((1, n), 0.3), np.zeros((1, n))
+    with pytest.raises(ValueError):
+        O.rhs(dataclasses.replace(om, model=M.MODEL_RICHARDS), vl, ti)
+    with pytest.raises(ValueError):
+        O.rhs(dataclasses.replace(om, model=M.MODEL_HEAT), vl, ti, np.full((1, n), 1e7))
