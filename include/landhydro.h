@@ -271,10 +271,10 @@ int lh_ssprk33_stage(lh_ctx*, int32_t stage, lh_state* Y, lh_state* U, const lh_
 /* Placement tuning -- no counterpart in the reference (host arrays have no such
  * effect).  The speed of the column launch on MI355X depends on where in HBM the
  * planes it streams together sit relative to each other (a few discrete rates,
- * ~12 % apart, reproducible for a given set of plane slots, also seen by a plain
- * device copy).  This call times the real launch on the data in Y with the
- * WRITTEN state in up to max_candidates (0 = default 6) different slot sets and
- * keeps the fastest:
+ * up to ~10 % apart, reproducible for a given set of plane slots, also seen by a plain
+ * device copy; cause not identified).  This call times the real launch on the
+ * data in Y with the WRITTEN planes in up to max_candidates (0 = default 6) different slot
+ * sets -- all written planes together, then each on its own -- and keeps the fastest:
  *   dY != NULL: the tendency launch of lh_rhs / lh_rhs_stable_dt writing dY;
  *   dY == NULL: the fused SSPRK33 stages of lh_step_ssprk33* writing the context's
  *               internal stage state (the trial stages run with dt = 0).
@@ -284,8 +284,9 @@ int lh_ssprk33_stage(lh_ctx*, int32_t stage, lh_state* Y, lh_state* U, const lh_
  * lh_state_device_ptr for a moved state (dY; Y with LH_PLACE_MOVE_INPUT) are
  * stale.  Results of later launches do not depend on the placement.  One-off cost:
  * ~12 launches per candidate and (max_candidates-1) temporary copies of the moved
- * state.  ms_before/ms_after (optional): launch time with the original and the
- * chosen placement.  Synchronises. */
+ * planes, never more than 25 % of the free device memory (LH_TUNE place_mem=PCT).
+ * ms_before/ms_after (optional): launch time with the original and the
+ * chosen placement.  Synchronises.  Always explicit: no other entry point tunes. */
 #define LH_PLACE_MOVE_INPUT 1u
 int lh_tune_placement(lh_ctx*, lh_state* Y, const lh_state* Ya, lh_state* dY, int max_candidates,
                       uint32_t flags, float* ms_before, float* ms_after);

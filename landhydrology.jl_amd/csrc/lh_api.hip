@@ -306,6 +306,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "persist=")) && sscanf(q + 8, "%d", &v) == 1 && v >= 0 && v <= 2) tu.persist = v;
     if ((q = strstr(t, "graph=")) && sscanf(q + 6, "%d", &v) == 1 && (v == 0 || v == 1)) tu.graph = v;
     if ((q = strstr(t, "seg=")) && sscanf(q + 4, "%d", &v) == 1 && v >= -1 && v <= 4096) tu.seg = v;
+    if ((q = strstr(t, "place_mem=")) && sscanf(q + 10, "%d", &v) == 1 && v >= 1 && v <= 90) tu.place_mem = v;
     if ((q = strstr(t, "zero=")) && sscanf(q + 5, "%d", &v) == 1 && (v == 0 || v == 1)) tu.zero = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 1024 && v % 64 == 0) tu.block = v;
@@ -666,7 +667,10 @@ int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_
     LH_HIP(c, hipMemGetInfo(&free_b, &total_b));
     const size_t per_cand = (bytes + (size_t(4) << 20)) * size_t(nplanes);
     const size_t arena_b = (bytes + (size_t(4) << 20)) * ARENA_SLOTS;
-    while (K > 1 && size_t(K - 1) * per_cand + 2 * arena_b > free_b / 2) --K;
+    // transient memory of the search: at most LH_TUNE place_mem=PCT percent of the free device
+    // memory (default 25)
+    const size_t budget = free_b / 100 * size_t(c->tune.place_mem > 0 ? c->tune.place_mem : 25);
+    while (K > 1 && size_t(K - 1) * per_cand + 2 * arena_b > budget) --K;
 
     // the trial launches must not leave their own mark in the status word
     uint32_t status_saved = 0;
@@ -674,7 +678,13 @@ int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_
     LH_HIP(c, hipStreamSynchronize(c->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     LH_HIP(c, hipEventCreate(&e0));
-    LH_HIP(c, hipEventCreate(&e1));
+    {
+        const hipError_t ee = hipEventCreate(&e1);
+        if (ee != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return fail(c, LH_ENODEVICE, "hipEventCreate failed: %s", hipGetErrorString(ee));
+        }
+    }
     int rc = LH_OK;
     auto timed = [&](float& ms) -> int {
         constexpr int REPS = 5;
@@ -1446,30 +1456,20 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
     // The written planes matter most (two write streams in an unlucky relative position cost
     // ~12 %; reads hardly care): first the written state as a whole, then each of its planes
     // on its own against the others, then -- if allowed -- the read state.
+    // (a tendency state's theta_i plane is never written -- d theta_i = 0 is kept by the zero bits --
+    // so it does not take part)
     float b0 = 0, a0 = 0, b1 = 0, a1 = 0;
-    if ((rc = tune_state_planes(c, written, ~0u, max_candidates, false, run, &b0, &a0))) return rc;
+    uint32_t wmask = 0;
+    for (int i = 0; i < LH_NVARS; ++i)
+        if (written->plane[i] && !(dY && i == LH_VAR_THETA_I)) wmask |= 1u << i;
+    if ((rc = tune_state_planes(c, written, wmask, max_candidates, false, run, &b0, &a0))) return rc;
     int nwritten = 0;
-    for (int i = 0; i < LH_NVARS; ++i) nwritten += written->plane[i] != nullptr;
+    for (int i = 0; i < LH_NVARS; ++i) nwritten += (wmask >> i) & 1u;
     for (int i = 0; i < LH_NVARS && nwritten > 1; ++i)
-        if (written->plane[i]) {
+        if (wmask >> i & 1u) {
             if ((rc = tune_state_planes(c, written, 1u << i, max_candidates, false, run, &b1, &a1))) return rc;
             if (a1 < a0) a0 = a1; // b1 re-measures the placement a0 was measured on
         }
-    // Most fresh memory is of one kind; if the tendency launch still sits below 70 % of the
-    // HBM peak by its algorithmic bytes, look once more, eight times as far (stopping at the
-    // first candidate that gets there).
-    if (dY && nwritten > 1) {
-        int nread = 0;
-        for (int i = 0; i < LH_NVARS; ++i) nread += Y->plane[i] != nullptr;
-        const double bytes = double(nread + nwritten) * double(c->cfg.ncols) * double(c->cfg.nlev) * double(c->esize);
-        const int K = (max_candidates > 0 ? max_candidates : 6) * 8;
-        const float goal_ms = float(bytes / (0.70 * 8.0e12) * 1e3);
-        for (int i = 0; i < LH_NVARS && a0 > goal_ms; ++i)
-            if (written->plane[i]) {
-                if ((rc = tune_state_planes(c, written, 1u << i, K, false, run, &b1, &a1, goal_ms))) return rc;
-                if (a1 < a0) a0 = a1;
-            }
-    }
     if (flags & LH_PLACE_MOVE_INPUT) {
         if ((rc = tune_state_planes(c, Y, ~0u, max_candidates, true, run, &b1, &a1))) return rc;
         if (a1 < a0) a0 = a1;

@@ -41,7 +41,9 @@ constexpr int rhs_waves_per_simd() {
     if (PERCOL) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE) return LH_RHS_WAVES_PER_SIMD; // no ice ring: fits 64 VGPRs in every mode
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
-    if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? 7 : 1;
+    // (the Float32 coupled tendency + step bound needs ~90 VGPRs: held to 72 it spills 18 values
+    // per level to scratch and runs 0.34 instead of 0.2x ms on 1e6 x 64)
+    if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? (MODE == 4 ? 5 : 7) : 1;
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
 }

@@ -24,6 +24,7 @@ struct Tune {
     int persist = 1; // persistent column stepper (0: fused-stage launches instead)
     int graph = 1;   // replay blocks of fused SSPRK33 steps of small ensembles as a hipGraph (0: plain launches)
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
+    int place_mem = 0;  // lh_tune_placement: transient memory bound, percent of free memory (0 = 25)
     int zero = 1;    // use the states' known-zero plane bits (0: always read theta_i and store d theta_i = 0)
 };
 

@@ -715,21 +715,22 @@ def default_initial_conditions(model: SoilModel):
     return initialize_states(model, ic, FT(0.0))
 
 
-# Ensembles whose planes reach this size get their written states placed by
-# measurement (lh_tune_placement) the first time they are used; LH_PLACEMENT_TUNE=0
-# switches that off.
+# Placement tuning (lh_tune_placement) is explicit: call `tune_placement(model, Y, Ya, dY)` once
+# per (Y, dY) pair of a large ensemble.  LH_PLACEMENT_TUNE=1 opts in to the host mirror doing it
+# by itself on the first rhs! / step of ensembles whose planes reach this size -- never moving
+# the input state (device pointers a user holds for Y stay valid).
 PLACEMENT_TUNE_MIN_PLANE_BYTES = 32 << 20
 
 
 def _placement_tuning_wanted(model: SoilModel) -> bool:
     d = model.domain
-    if os.environ.get("LH_PLACEMENT_TUNE", "1") == "0":
+    if os.environ.get("LH_PLACEMENT_TUNE", "0") != "1":
         return False
     return d.ncolumns * d.nelements * np.dtype(d.FT).itemsize >= PLACEMENT_TUNE_MIN_PLANE_BYTES
 
 
 def tune_placement(model: SoilModel, Y: "FieldVector", Ya=None, dY: Optional["FieldVector"] = None,
-                   max_candidates: int = 0, move_input: bool = True):
+                   max_candidates: int = 0, move_input: bool = False):
     """Build extension (no counterpart in the reference): let the library choose, by
     timing the real launch, where in HBM the state written by rhs! (dY given) or the
     SSPRK33 stage state (dY=None) lives -- lh_tune_placement.  Returns the launch
@@ -768,8 +769,7 @@ def make_rhs(model: SoilModel):
         ya = Ya.handle if isinstance(Ya, FieldVector) else None
         if placed is not None and (id(Y), id(dY)) not in placed:
             placed.add((id(Y), id(dY)))
-            F.check(L.lh_tune_placement(be.ctx, Y.handle, ya, dY.handle, 0, F.LH_PLACE_MOVE_INPUT,
-                                        None, None), be.ctx)
+            F.check(L.lh_tune_placement(be.ctx, Y.handle, ya, dY.handle, 0, 0, None, None), be.ctx)
         F.check(L.lh_rhs(be.ctx, float(t), Y.handle, ya, dY.handle), be.ctx)
         return dY
 
@@ -960,8 +960,7 @@ def _advance(sim: Simulation, nsteps: int):
     be.set_bcs(model, it.t)
     if not getattr(it, "_placed", False) and _placement_tuning_wanted(model):
         it._placed = True
-        F.check(L.lh_tune_placement(be.ctx, it.u.handle, ya, None, 0, F.LH_PLACE_MOVE_INPUT, None, None),
-                be.ctx)
+        F.check(L.lh_tune_placement(be.ctx, it.u.handle, ya, None, 0, 0, None, None), be.ctx)
     F.check(L.lh_step_ssprk33(be.ctx, it.u.handle, ya, it.t, it.dt, nsteps,
                               bcv.ctypes.data_as(C.POINTER(C.c_double)) if bcv is not None
                               else None), be.ctx)

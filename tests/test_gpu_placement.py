@@ -121,7 +121,7 @@ def test_rejects_bad_arguments():
         assert L.lh_tune_placement(g.ctx, Y, Ya, None, 0, 0x80, None, None) == F.LH_EINVAL
 
 
-def test_host_mirror_tunes_large_ensembles_only(monkeypatch):
+def test_host_mirror_tunes_on_request_and_large_ensembles_only(monkeypatch):
     lh = pc._pkg()
     soil = lh.soil
     calls = []
@@ -147,15 +147,23 @@ def test_host_mirror_tunes_large_ensembles_only(monkeypatch):
     small = model(64)
     Y, Ya = lh.initialize_states(small, ic, 0.0)
     dY = Y.similar()
+    monkeypatch.delenv("LH_PLACEMENT_TUNE", raising=False)
+    monkeypatch.setattr(soil, "PLACEMENT_TUNE_MIN_PLANE_BYTES", 1)
     rhs = lh.make_rhs(small)
     rhs(dY, Y, Ya, 0.0)
-    assert calls == []
+    assert calls == []                                # implicit tuning is opt-in (LH_PLACEMENT_TUNE=1)
+    monkeypatch.setenv("LH_PLACEMENT_TUNE", "1")
+    monkeypatch.setattr(soil, "PLACEMENT_TUNE_MIN_PLANE_BYTES", 32 << 20)
+    rhs = lh.make_rhs(small)
+    rhs(dY, Y, Ya, 0.0)
+    assert calls == []                                # ... and for large ensembles only
     monkeypatch.setattr(soil, "PLACEMENT_TUNE_MIN_PLANE_BYTES", 1)
     rhs = lh.make_rhs(small)
     rhs(dY, Y, Ya, 0.0)
     first = dY.get("ϑ_l").copy()
     rhs(dY, Y, Ya, 0.0)
     assert len(calls) == 1                            # once per (Y, dY) pair
+    assert calls[0][5] == 0                           # never LH_PLACE_MOVE_INPUT by itself
     np.testing.assert_array_equal(first, dY.get("ϑ_l"))
     sim = lh.Simulation(small, lh.SSPRK33(), Y_init=Y, dt=1.0, tspan=(0.0, 3.0), Ya_init=Ya)
     lh.run(sim)
