@@ -382,12 +382,12 @@ def main():
 
     # HBM bytes per launch from committed PMC passes of this same command line (rocprofv3 cannot
     # run inside the timed process): profiles/pmc_traffic.json, written by tools/gpu_profile.sh
-    traffic, traffic_source, valu_per_cell = None, None, None
+    traffic, traffic_source, traffic_command, valu_per_cell = None, None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tr = json.load(fh).get(a.workload + ("_nozero" if a.no_known_zero else ""))
         if tr and tr["ncols"] == a.ncols and tr["nlev"] == nlev and tr.get("known_zero", True) != a.no_known_zero:
-            traffic, traffic_source = tr["total_bytes"], tr.get("source")
+            traffic, traffic_source, traffic_command = tr["total_bytes"], tr.get("source"), tr.get("command")
             valu_per_cell = tr.get("valu_per_cell")
     except (OSError, ValueError, KeyError):
         pass
@@ -420,6 +420,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      "frac_is": "bytes_moved_per_launch / ms_per_step / peak (the timed loop, wall clock)",
                      "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_is": "PROFILED, not measured by this run: per-launch HBM bytes of the same kernel on the "
+                                   "same workload/size from committed rocprofv3 PMC passes (null when they differ)",
+                     "traffic_command": traffic_command,
                      "bytes_per_cell": bytes_per_cell, "bytes_moved_per_cell": moved_per_cell,
                      "planes_read": nr, "planes_written": nw, "theta_i_known_zero": bool(noice),
                      "bytes_moved_per_launch": bytes_moved,
