@@ -126,7 +126,7 @@ struct KCfg {
     static constexpr bool NT = NT_, SEG = SEG_;
 };
 
-// Stage the log2/exp2 tables of MathFast<double> in LDS (5 KiB per workgroup);
+// Stage the log2/exp2 tables of MathFast<double> in LDS (48 KiB per workgroup);
 // every thread of the block must call this before any thread leaves.
 template <typename M>
 __device__ __forceinline__ MathTables stage_math_tables(const double* gtab, double* lds) {
