@@ -239,7 +239,10 @@ int lh_rhs(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* d
  * (the rule of lh_stable_dt) left in device memory (one FT value): the input of
  * the RCCL min all-reduce costs no second sweep over the columns.  With a
  * communicator attached (lh_comm_init) that all-reduce is enqueued right behind
- * the launch and the value is the global minimum. */
+ * the launch and the value is the global minimum.  The fused bound accumulates the
+ * face diffusivities in Float32 whatever the working type (a safety estimate under
+ * a Courant factor): it agrees with lh_stable_dt to 1e-6 relative, and -- a maximum
+ * being exact -- does not depend on how the columns are dealt to waves or ranks. */
 int lh_rhs_stable_dt(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY,
                      double courant, void* dt_device_ft);
 

@@ -133,14 +133,23 @@ __device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<
 // psi takes its own log2(Se), 2^(.), log2(1 - .).
 // WANT_DPSI additionally returns dpsi/dvl for the stable-step bound: with
 // u = S^(-1/m) - 1 = w/t the van Genuchten slope |psi| (u+1)/(n m u Se (nu_eff - theta_r))
-// collapses to |psi| / (n m w (vl_safe - theta_r)); 1/S_s when saturated.
+// collapses to |psi| / (n m w (vl_safe - theta_r)); 1/S_s when saturated.  It is returned TIMES
+// n m (a column constant the caller divides out once per column) and in Float32 whatever FT is
+// (slope32): the bound is a safety estimate under a Courant factor <= 1/2, seven digits are
+// plenty, and a Float64 reciprocal alone costs nine issue slots per cell.
 // NOICE: the ice plane of the state is known to be all zeros (lh_state zero bits): ti is the
 // literal 0, nu_eff == nu, and the separate psi saturation never exists -- the same numbers as
 // the general path produces for ti == 0, with the ice code compiled out.
+// -psi / q in Float32 (v_cvt_f32_f64 x2, v_rcp_f32, v_mul_f32 with a negated operand)
+template <typename FT>
+__device__ __forceinline__ float slope32(FT psi, FT q) {
+    return -float(psi) * __builtin_amdgcn_rcpf(float(q));
+}
+
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                                   FT& psi, FT* dpsi = nullptr) {
+                                                   FT& psi, float* dpsi = nullptr) {
     const FT nu_eff = NOICE ? c.nu : c.nu - ti;
     // max(vl, theta_r + eps), NaN kept (a compare and two 32-bit selects; v_max + a NaN put back
     // by 0 * vl costs the same once the canonicalising v_max or the asm hazard nop is counted)
@@ -159,7 +168,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         K = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
         if (WANT_PSI && same) {
             psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
-            if (WANT_DPSI) *dpsi = -psi * mm.rcp(c.n * c.m * w * num);
+            if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
         }
     } else {
         // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
@@ -169,7 +178,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             FT ps = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
             asm volatile("" : "+v"(ps));
             psi = ps;
-            if (WANT_DPSI) *dpsi = c.inv_S_s;
+            if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
     if (!NOICE && WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
@@ -179,10 +188,10 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             const FT we = FT(1) - mm.exp2_scaled(ae);
             const FT Lwe = mm.log2(we);
             psi = -mm.exp2_scaled(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
-            if (WANT_DPSI) *dpsi = -psi * mm.rcp(c.n * c.m * we * num);
+            if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
         } else {
             psi = (Se == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
-            if (WANT_DPSI) *dpsi = c.inv_S_s;
+            if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
     if (FACTORS) {
@@ -202,7 +211,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                               FT& psi, FT* dpsi = nullptr) {
+                                               FT& psi, float* dpsi = nullptr) {
     if (M::is_production) {
         water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE>(mm, P, c, vl, ti, T, K, psi, dpsi);
     } else {
@@ -213,9 +222,9 @@ __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>&
             const FT Se = (vls - c.theta_r) / (nu_eff - c.theta_r);
             const FT u = mm.pow(Se, -c.inv_m) - FT(1);
             if (Se <= FT(1) && u > FT(0))
-                *dpsi = fabs(psi) * (u + FT(1)) / (c.n * c.m * u * Se * (nu_eff - c.theta_r));
+                *dpsi = float(fabs(psi) * (u + FT(1)) / (u * Se * (nu_eff - c.theta_r)));
             else
-                *dpsi = FT(1) / c.S_s;
+                *dpsi = float(c.n * c.m / c.S_s);
         }
     }
 }

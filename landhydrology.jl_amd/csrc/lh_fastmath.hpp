@@ -165,16 +165,16 @@ template <> struct MathFast<double> {
         double res = exp2_scaled(x * (1.4426950408889634 * EXP2_SCALE));
         return (x != x) ? x : res;
     }
-    // sqrt of a positive normal x: v_rsq_f64 seed, one coupled Newton step and a
+    // sqrt of a positive normal x: v_rsq_f64 seed, one Newton step on g = sqrt(x) and a
     // final residual correction (no range scaling: the closures take sqrt(S),
-    // S in [eps, 1))
+    // S in [eps, 1)).  h = 1/(2 sqrt x) stays at the seed's accuracy: it only scales the
+    // residual d, which is already below 2^-40 of g.
     static __device__ __forceinline__ double sqrt(double x) {
         const double y = __builtin_amdgcn_rsq(x);
         double g = x * y;
-        double h = 0.5 * y;
+        const double h = 0.5 * y;
         const double r = __builtin_fma(-h, g, 0.5);
         g = __builtin_fma(g, r, g);
-        h = __builtin_fma(h, r, h);
         const double d = __builtin_fma(-g, g, x);
         return __builtin_fma(d, h, g);
     }

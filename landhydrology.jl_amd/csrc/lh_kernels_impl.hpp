@@ -150,6 +150,13 @@ __device__ __forceinline__ float fmax_ft(float a, float b) { return __builtin_fm
 __device__ __forceinline__ double fmin_ft(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float fmin_ft(float a, float b) { return __builtin_fminf(a, b); }
 
+// max of two NON-NEGATIVE floats as a signed-integer max of their bit patterns (they order alike;
+// -0.0 and negative values lose, a NaN wins and is dropped with its lane at the end): one
+// v_max_i32 / v_max3_i32, where fmaxf costs a canonicalising v_max_f32 per operand on top
+__device__ __forceinline__ float max_nonneg(float a, float b) {
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
+}
+
 template <typename FT>
 __device__ __forceinline__ bool finite(FT x) {
     return x - x == FT(0);
@@ -215,8 +222,8 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     // MODE 4: one LDS word per thread for the wave-level maximum of the face diffusivities
     // (after the level coordinates, 16-byte aligned); lanes past the last column leave the
     // neutral 0 there
-    FT* s_red = reinterpret_cast<FT*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
-    if (WANT_DT) s_red[threadIdx.x] = FT(0);
+    float* s_red = reinterpret_cast<float*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
+    if (WANT_DT) s_red[threadIdx.x] = 0.0f;
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
 
@@ -288,7 +295,11 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
     FT nf_acc = FT(0); // += 0 * tendency: becomes NaN once any tendency is non-finite
-    FT dpsi_p[CPL], rcs_p[CPL], Dmax[CPL]; // MODE 4: stable-step bookkeeping
+    // MODE 4: stable-step bookkeeping, in Float32 whatever FT is (see slope32): n m d psi / d vl
+    // and 1 / rho_c_s of the previous cell, and the lane's maxima of TWICE the water (x n m) and
+    // heat face diffusivities (the column constant n m and the exact factor 1/2 of the mean
+    // coefficients are divided out once per column / wave at the end)
+    float dpsi_p[CPL], ircs_p[CPL], DmaxW[CPL], DmaxT[CPL];
 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -296,8 +307,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         vl_p[j] = re_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
         Ta[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
-        dpsi_p[j] = Dmax[j] = FT(0);
-        rcs_p[j] = FT(1);
+        dpsi_p[j] = DmaxW[j] = DmaxT[j] = ircs_p[j] = 0.0f;
     }
     // loads the level the row pointers currently address into ring slot `slot`,
     // then moves the pointers one level up
@@ -385,16 +395,19 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         }
         if (i + PF < i_end) fetch(k); // keep PF levels in flight ahead of the one computed
         const FT z = s_zc[i];
-        FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], dpsi[CPL], rcs[CPL];
+        FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], rcs[CPL];
+        float dpsi[CPL], ircs[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             T[j] = Ta[j];
             kap[j] = FT(0);
-            K[j] = psi[j] = h[j] = E[j] = dpsi[j] = FT(0);
+            K[j] = psi[j] = h[j] = E[j] = FT(0);
+            dpsi[j] = ircs[j] = 0.0f;
             rcs[j] = FT(1);
             if (HEAT) {
                 T[j] = temperature_closure<FT, M, NOICE>(mm, P, c[j], vl[j], ti[j], re[j], rcs[j]);
                 kap[j] = kappa_closure<FT, M, NOICE>(mm, P, c[j], vl[j], ti[j]);
+                if (WANT_DT) ircs[j] = float(mm.rcp(rcs[j])); // (the reciprocal temperature_closure formed)
             }
             if (WATER) {
                 water_closures<FT, M, FACTORS, true, WANT_DT, NOICE>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
@@ -402,17 +415,9 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
-            if (WANT_DT) { // the rule of stable_dt_kernel, per cell / per interior face
-                FT D = FT(0);
-                if (i == 0 || i == n - 1) {
-                    D = K[j] * dpsi[j];
-                    if (HEAT) D = fmax_ft(D, kap[j] * mm.rcp(rcs[j]));
-                }
-                if (i > i_first) {
-                    D = fmax_ft(D, (K_p[j] + K[j]) * FT(0.5) * fmax_ft(dpsi_p[j], dpsi[j]));
-                    if (HEAT) D = fmax_ft(D, (kap_p[j] + kap[j]) * FT(0.5) * mm.rcp(fmin_ft(rcs_p[j], rcs[j])));
-                }
-                Dmax[j] = fmax_ft(Dmax[j], D);
+            if (WANT_DT && i > i_first) { // the rule of stable_dt_kernel per interior face (x 2)
+                if (WATER) DmaxW[j] = max_nonneg(DmaxW[j], float(K_p[j] + K[j]) * max_nonneg(dpsi_p[j], dpsi[j]));
+                if (HEAT) DmaxT[j] = max_nonneg(DmaxT[j], float(kap_p[j] + kap[j]) * max_nonneg(ircs_p[j], ircs[j]));
             }
         }
         if (i == 0) {
@@ -421,9 +426,13 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
                 FT K_f = FT(0), kap_f = FT(0);
                 boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
                                                               T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f);
-                if (WANT_DT) { // Dirichlet faces: half a cell away, face-state coefficients
-                    Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K[j] : FT(0)) * dpsi[j]);
-                    if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0)) * mm.rcp(rcs[j]));
+                if (WANT_DT) { // the bottom cell's own coefficients; Dirichlet faces: half a cell away, face-state coefficients
+                    DmaxW[j] = max_nonneg(DmaxW[j], 2.0f * float(K[j]) * dpsi[j]);
+                    DmaxW[j] = max_nonneg(DmaxW[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K[j] : FT(0))) * dpsi[j]);
+                    if (HEAT) {
+                        DmaxT[j] = max_nonneg(DmaxT[j], 2.0f * float(kap[j]) * ircs[j]);
+                        DmaxT[j] = max_nonneg(DmaxT[j], 4.0f * float(fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0))) * ircs[j]);
+                    }
                 }
             }
         } else if (!SEG || i > i_first) { // (the cell below a segment only primes the *_p values)
@@ -464,7 +473,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             E_p[j] = E[j];
             if (WANT_DT) {
                 dpsi_p[j] = dpsi[j];
-                rcs_p[j] = rcs[j];
+                ircs_p[j] = ircs[j];
             }
         }
       }
@@ -476,9 +485,13 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
             FT K_f = FT(0), kap_f = FT(0);
             boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
                                                           K_p[j], psi_p[j], Fe[j], Fw[j], &K_f, &kap_f);
-            if (WANT_DT) {
-                Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(K_f, K_f > FT(0) ? K_p[j] : FT(0)) * dpsi_p[j]);
-                if (HEAT) Dmax[j] = fmax_ft(Dmax[j], FT(2) * fmax_ft(kap_f, kap_f > FT(0) ? kap_p[j] : FT(0)) * mm.rcp(rcs_p[j]));
+            if (WANT_DT) { // the top cell's own coefficients, and the Dirichlet face's
+                DmaxW[j] = max_nonneg(DmaxW[j], 2.0f * float(K_p[j]) * dpsi_p[j]);
+                DmaxW[j] = max_nonneg(DmaxW[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K_p[j] : FT(0))) * dpsi_p[j]);
+                if (HEAT) {
+                    DmaxT[j] = max_nonneg(DmaxT[j], 2.0f * float(kap_p[j]) * ircs_p[j]);
+                    DmaxT[j] = max_nonneg(DmaxT[j], 4.0f * float(fmax_ft(kap_f, kap_f > FT(0) ? kap_p[j] : FT(0))) * ircs_p[j]);
+                }
             }
         }
         emit(Fw, Fe, vl_p, re_p);
@@ -486,30 +499,33 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     if (nf_acc != nf_acc) atomicOr(P.status, 1u);
     if (WANT_DT) { // dt = courant dz^2 / (max D over the wave's columns), one atomicMin per wave
         using U = typename Bits<FT>::type;
-        FT dmax = FT(0);
+        float dmax = 0.0f;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
-            if (CPL == 1 || col0 + j < P.ncols) dmax = fmax_ft(dmax, Dmax[j]);
+        for (int j = 0; j < CPL; ++j) { // (a column whose maximum is NaN is dropped: it is flagged through P.status)
+            const float Dj = max_nonneg(DmaxW[j] * float(FT(1) / (c[j].n * c[j].m)), DmaxT[j]);
+            if ((CPL == 1 || col0 + j < P.ncols) && Dj == Dj) dmax = max_nonneg(dmax, Dj);
+        }
         // Wave maximum by a binary tree through LDS (x -> fl(c/x) is monotone, so the minimum of
-        // the lanes' quotients IS the quotient of the maximum: one division per wave).  Lanes past
-        // the last column returned early -- a cross-lane shuffle could read their dead registers;
-        // their LDS words hold the neutral 0 from the prologue.  The lanes still here are a prefix
-        // of the wave (col0 grows with the lane), so lane l < off always has its partner's word to
-        // read.  One wave = one 64-word segment; the LDS operations of a wave execute in order, so
-        // the wave barriers only pin the compiler's ordering.
-        FT* seg = s_red + (threadIdx.x & ~63u);
+        // the lanes' quotients IS the quotient of the maximum: one division per wave; a maximum
+        // is exact, so the result does not depend on how columns are dealt to waves or ranks).
+        // Lanes past the last column returned early -- a cross-lane shuffle could read their dead
+        // registers; their LDS words hold the neutral 0 from the prologue.  The lanes still here
+        // are a prefix of the wave (col0 grows with the lane), so lane l < off always has its
+        // partner's word to read.  One wave = one 64-word segment; the LDS operations of a wave
+        // execute in order, so the wave barriers only pin the compiler's ordering.
+        float* seg = s_red + (threadIdx.x & ~63u);
         const unsigned l = threadIdx.x & 63u;
         seg[l] = dmax;
 #pragma unroll
         for (unsigned off = 32; off > 0; off >>= 1) {
             __builtin_amdgcn_wave_barrier();
             if (l < off) {
-                dmax = fmax_ft(dmax, seg[l + off]);
+                dmax = max_nonneg(dmax, seg[l + off]);
                 seg[l] = dmax;
             }
         }
-        if (l == 0 && dmax > FT(0)) {
-            const FT best = (dt * P.dz * P.dz) / dmax;
+        if (l == 0 && dmax > 0.0f) {
+            const FT best = (FT(2) * dt * P.dz * P.dz) / FT(dmax); // dmax = twice the diffusivity
             U b;
             __builtin_memcpy(&b, &best, sizeof(FT));
             atomicMin(reinterpret_cast<U*>(P.dt_out), b);

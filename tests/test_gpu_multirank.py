@@ -93,7 +93,7 @@ def test_native_rccl_communicator_single_rank(name):
         F.check(L.lh_allreduce_min(ctx, t1.data_ptr()), ctx)
         F.check(L.lh_synchronize(ctx), ctx)
         assert t1.item() == t0.item() and t0.item() > 0
-        assert abs(host.value - t0.item()) <= (1e-11 if case.dtype == np.float64 else 2e-4) * t0.item()
+        assert abs(host.value - t0.item()) <= (1e-6 if case.dtype == np.float64 else 2e-4) * t0.item()
         again = g.tendencies(dY)
         for k in base:
             assert np.array_equal(base[k], again[k])

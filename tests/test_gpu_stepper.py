@@ -363,7 +363,9 @@ def _pkg():
                                   "mixed_smooth_f32"])
 def test_fused_rhs_stable_dt(name):
     """lh_rhs_stable_dt = lh_rhs (same tendencies, bit for bit) + the stable-step bound of
-    lh_stable_dt / the oracle's rule from the same pass."""
+    lh_stable_dt / the oracle's rule from the same pass.  The fused bound is accumulated in
+    Float32 whatever the working type (a safety estimate under a Courant factor: lh_closures.hpp
+    slope32), so it agrees with the Float64 rule to Float32 rounding: 1e-6 relative."""
     import torch
     case = pc.make_case(name, ncols=None if name != "c1_dirichlet_f64" else 7)
     want_dt = O.stable_dt(case.om, case.vl, case.ti, case.rhoe, 0.5, case.T_aux)
@@ -382,7 +384,7 @@ def test_fused_rhs_stable_dt(name):
         sep = C.c_double()
         F.check(g.L.lh_stable_dt(g.ctx, Y, Ya, 0.5, C.byref(sep)), g.ctx)
     got = float(tdt.item())
-    rel = 1e-11 if case.dtype == np.float64 else 2e-4
+    rel = 1e-6 if case.dtype == np.float64 else 2e-4
     assert abs(got - want_dt) <= rel * want_dt, (name, got, want_dt)
     assert abs(got - sep.value) <= rel * want_dt, (name, got, sep.value)
 
