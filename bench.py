@@ -278,8 +278,23 @@ def main():
     # id, and carries the collective itself only in the gloo rehearsal (ranks sharing one GPU
     # cannot form an RCCL communicator).
     native_comm = world > 1 and a.backend == "nccl"
+    comm_note = None
     if native_comm:
-        pkg.partition.attach_native_comm(ctx, rank, world)
+        # every rank must take the same route: agree on the outcome of lh_comm_init before using it
+        ok = 1
+        try:
+            pkg.partition.attach_native_comm(ctx, rank, world)
+        except Exception as e:      # noqa: BLE001
+            ok, comm_note = 0, repr(e)
+            print(f"bench.py rank {rank}: lh_comm_init failed ({e!r}); falling back to torch.distributed "
+                  f"for the min all-reduce if any rank failed", file=sys.stderr)
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                F.check(L.lh_comm_destroy(ctx), ctx)
+            native_comm = False
+            comm_note = comm_note or "another rank failed to attach the native communicator"
 
     # optional one-off setup (--placement-tune): the library places the written state in HBM by
     # measurement (lh_tune_placement); the default line is measured on the first-come placement
@@ -417,7 +432,8 @@ def main():
                    "every 3rd eval also yields the rank's stable dt (fused)" +
                    ((f"; min all-reduce of that value: " +
                      ("RCCL inside the library (lh_comm_init, ncclAllReduce on the launch stream)" if native_comm
-                      else f"torch.distributed {a.backend} (rehearsal on a shared GPU)")) if world > 1 else "")},
+                      else f"torch.distributed {a.backend}" + (" (rehearsal on a shared GPU)" if a.backend == "gloo"
+                                                                else f" (native communicator unavailable: {comm_note})"))) if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "frac_is": "bytes_moved_per_launch / ms_per_step / peak (the timed loop, wall clock)",

@@ -231,6 +231,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_S_s = FT(1) / u.S_s;
     u.inv_nu = FT(1) / u.nu;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
+    u.l2_por = FT(0); // filled on the device by finish_colc (the device math policy's own log2)
     {   // exponent multipliers in the exp2 unit of the production math (lh_fastmath.hpp)
         const FT sc = sizeof(FT) == 8 ? FT(MathFast<double>::EXP2_SCALE) : FT(1);
         u.e_one = sc;

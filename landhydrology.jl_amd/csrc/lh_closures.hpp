@@ -146,10 +146,25 @@ __device__ __forceinline__ float slope32(FT psi, FT q) {
     return -float(psi) * __builtin_amdgcn_rcpf(float(q));
 }
 
+// log2(nu - theta_r) by the math policy's own log2: with it log2 Se = log2 S + (l2_por -
+// log2(nu_eff - theta_r)) is EXACTLY log2 S for a lane without ice (nu_eff == nu bitwise), so the
+// per-lane psi chain of a wave with ice reproduces the shared chain bit for bit on its ice-free lanes
+template <typename FT, typename M>
+__device__ __forceinline__ void finish_colc(const M& mm, ColC<FT>& c) {
+    const FT por = c.nu - c.theta_r;
+    c.l2_por = (M::is_production && por > FT(0)) ? mm.log2(por) : FT(0);
+}
+
+// every active lane of the wave has the predicate (one s_and/s_cmp on the ballot)
+__device__ __forceinline__ bool wave_all(bool pred) {
+    return __builtin_amdgcn_ballot_w64(!pred) == 0ull;
+}
+
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                    FT& psi, float* dpsi = nullptr) {
+    constexpr FT SC = FT(M::EXP2_SCALE);
     const FT nu_eff = NOICE ? c.nu : c.nu - ti;
     // max(vl, theta_r + eps), NaN kept (a compare and two 32-bit selects; v_max + a NaN put back
     // by 0 * vl costs the same once the canonicalising v_max or the asm hazard nop is counted)
@@ -157,45 +172,64 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     const FT num = vls - c.theta_r;
     const FT S = num * c.inv_por;
     const bool same = NOICE || (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
+    const bool unsat = S < FT(1);
+    // psi's own saturation Se = num / (nu_eff - theta_r) is never formed: Se < 1 <=> num < por_e,
+    // and log2 Se = log2 S + (log2(nu - theta_r) - log2 por_e) (one log2 instead of a reciprocal,
+    // a product and a log2)
+    const FT por_e = nu_eff - c.theta_r;
+    const bool unsat_e = (same & unsat) | (!same & (num < por_e)); // (mask logic: no selects)
+    // ONE decision per wave: without any ice lane K and psi share t = S^(1/m) and w = 1 - t; with
+    // one, every lane runs psi from its own saturation -- a lane-level choice would make a mixed
+    // wave run both chains one after the other.  Per-lane results do not depend on the choice
+    // (see finish_colc), so they do not depend on which cells share a wave either.
+    const bool shared = NOICE || wave_all(same);
 
     // exponents are formed in the exp2 unit of the policy (c.e_* carry the scale)
-    if (S < FT(1)) {
-        const FT L = mm.log2(S);
+    FT L = FT(0);   // log2 S of an unsaturated cell (0 otherwise: K_r = 1, and sqrt(S) = 2^0 below)
+    FT Kb;          // K without the conductivity factors (FACTORS: without sqrt(S) too)
+    if (unsat) {
+        L = mm.log2(S);
         const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
         const FT w = FT(1) - mm.exp2_scaled(a);
         const FT Lw = mm.log2(w);
         const FT inner = FT(1) - mm.exp2_scaled(c.e_m * Lw);
-        K = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
-        if (WANT_PSI && same) {
+        if (FACTORS) Kb = (inner * inner) * c.Ksat;
+        else Kb = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
+        if (WANT_PSI && shared) {
             psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
         }
     } else {
         // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
         // compiler evaluates it for every cell and selects, six VALU instructions per cell)
-        K = c.Ksat; // K_r = 1
-        if (WANT_PSI && same) {
+        Kb = c.Ksat; // K_r = 1
+        if (WANT_PSI && shared) {
             FT ps = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
             asm volatile("" : "+v"(ps));
             psi = ps;
             if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
-    if (!NOICE && WANT_PSI && !same) { // ice: psi has its own saturation (nu_eff) and its own logs
-        const FT Se = num * mm.rcp(nu_eff - c.theta_r);
-        if (Se < FT(1)) {
-            const FT ae = mm.log2(Se) * c.e_inv_m;
+    if (!NOICE && WANT_PSI && !shared) { // ice somewhere in the wave: psi from every lane's own saturation
+        if (unsat_e) {
+            // (unsat_e without unsat needs theta_i < 0: out of contract, L is 0 there)
+            const FT Le = L + (c.l2_por - mm.log2(por_e)); // log2 Se; == L bitwise for a lane without ice
+            const FT ae = Le * c.e_inv_m;
             const FT we = FT(1) - mm.exp2_scaled(ae);
             const FT Lwe = mm.log2(we);
             psi = -mm.exp2_scaled(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
         } else {
-            psi = (Se == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            const bool one = (same & (S == FT(1))) | (!same & (num == por_e));
+            FT ps = one ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            if (por_e < FT(0)) ps = FT(NAN); // Se < 0: `^` raises DomainError in the reference
+            asm volatile("" : "+v"(ps));
+            psi = ps;
             if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
     if (FACTORS) {
-        // exp(gamma (T - T_ref)) 10^(-Omega f_i) as ONE 2^(.): the two exponents add
+        // exp(gamma (T - T_ref)) 10^(-Omega f_i) sqrt(S) as ONE 2^(.): the three exponents add
         FT ex = FT(0);
         if (P.viscosity_kind) ex = (P.gamma * (T - P.T_ref_visc)) * FT(1.4426950408889634);
         if (P.impedance_kind) {
@@ -203,7 +237,9 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             const FT f_i = ti * mm.rcp(tl + ti); // 0/0 = NaN as in the reference
             ex = fma_ft(-P.Omega * f_i, FT(3.3219280948873623), ex);
         }
-        K = K * mm.exp2(ex);
+        K = Kb * mm.exp2_scaled(fma_ft(L, SC * FT(0.5), ex * SC));
+    } else {
+        K = Kb;
     }
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }

@@ -34,6 +34,11 @@ constexpr bool f32_coupled_vgpr_constants() {
     return sizeof(FT) == 8 || !FACTORS; // Float64 (no occupancy bound there): +2.5 % on f3c64
 }
 
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool NOICE>
+constexpr bool heat_vgpr_constants() {
+    return sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && M::is_production && !NOICE;
+}
+
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false>
 constexpr int rhs_waves_per_simd() {
     if (!M::is_production || FACTORS) return 1;
@@ -203,10 +208,26 @@ __device__ __forceinline__ bool finite(FT x) {
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false>
 __global__ void __launch_bounds__((rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()),
                                   (rhs_min_waves<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()))
-rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
+rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    constexpr bool TEND_MODE = (MODE == 0 || MODE == 4); // (the fused stages: measured slower with it)
+    // The Float64 heat kernels with conductivity factors or ice run at 3 waves/SIMD whatever they
+    // do (130 VGPRs) and need more uniform constants than there are SGPRs: the compiler spills the
+    // excess to VGPR lanes and reloads them with v_readlane in front of every use (20 VALU
+    // instructions per cell).  The constants of the heat closures held in VGPRs instead remove that.
+    DevParams<FT> P = P0;
+    if constexpr (heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() && TEND_MODE) {
+        auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
+        vr(P.rho_c_ds); vr(P.rhocp_l); vr(P.rhocp_i); vr(P.T_ref); vr(P.kappa_sat_unfrozen);
+        vr(P.l2_kappa_sat_unfrozen); vr(P.l2_kappa_sat_frozen); vr(P.kersten_exp_unfrozen);
+        vr(P.kersten_exp_frozen); vr(P.b);
+        if (MODE != 4) { // (the step-bound bookkeeping of MODE 4 needs the registers: 175 VGPRs = 2 waves/SIMD otherwise)
+            vr(P.rho_i); vr(P.LH_f0); vr(P.inv_dz); vr(P.half_inv_dz);
+            if (FACTORS) { vr(P.gamma); vr(P.T_ref_visc); vr(P.Omega); }
+        }
+    }
     constexpr int CPL = CFG::CPL, PF = CFG::PF;
     constexpr bool NT = CFG::NT;
     constexpr bool TEND = (MODE == 0 || MODE == 4); // writes a tendency (not a stage state)
@@ -276,6 +297,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
     for (int j = 0; j < CPL; ++j) {
         colj[j] = col0 + j < P.ncols ? col0 + j : P.ncols - 1;
         c[j] = make_colc<FT, M>(P, colj[j], PERCOL);
+        if (WATER && !NOICE) finish_colc<FT, M>(mm, c[j]);
     }
     // Float32 coupled tendency: with every uniform constant in SGPRs the kernel spills 45 of them
     // to VGPR lanes (28 v_readlane per two cells).  Thirteen column constants held in VGPRs
@@ -285,6 +307,7 @@ rhs_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, con
         ColC<FT>& q = c[0];
         vr(q.nu); vr(q.theta_lim); vr(q.theta_r); vr(q.inv_por); vr(q.e_inv_m); vr(q.e_m); vr(q.e_one);
         vr(q.e_inv_n); vr(q.e_log2_alpha); vr(q.Ksat); vr(q.inv_S_s); vr(q.inv_nu); vr(q.k_dry);
+        if (!NOICE) vr(q.l2_por);
 #pragma unroll
         for (int j = 1; j < CPL; ++j) c[j] = c[0];
     }
@@ -595,7 +618,8 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const bool cell = i < n && col_raw < P.ncols;
     const int ic = i < n ? i : n - 1;
     const int64_t col = col_raw < P.ncols ? col_raw : P.ncols - 1; // spare slots shadow the last column
-    const ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    if (WATER && !NOICE) finish_colc<FT, M>(mm, c);
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     // Planes are column-fastest, threads here are level-fastest: go through LDS tiles so that
     // global memory sees the cpb adjacent columns of a level as one contiguous piece.  All
@@ -749,7 +773,8 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
     const FT* p_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + col;
     const FT* p_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : IN.v[1]) + col;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
-    const ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    if (WATER) finish_colc<FT, M>(mm, c);
     for (int i = 0; i < P.nlev; ++i) {
         const int64_t o = int64_t(i) * P.stride;
         FT vl = p_vl[o], ti = p_ti[o];
@@ -786,7 +811,8 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
     if (col < P.ncols) {
         const FT* p_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + col;
         const FT* p_ti = (MODEL == MODEL_HEAT ? AUX.v[1] : IN.v[1]) + col;
-        const ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+        ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+        if (WATER) finish_colc<FT, M>(mm, c);
         const FT cdz2 = courant * P.dz * P.dz;
         const int n = P.nlev;
         FT K_p = FT(0), dpsi_p = FT(0), kap_p = FT(0), rcs_p = FT(1);

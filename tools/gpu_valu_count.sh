@@ -8,7 +8,7 @@ import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in acc.items():
     if "rhs_kernel" in k or "column_stepper" in k:
         iv=sum(v["SQ_INSTS_VALU"])/len(v["SQ_INSTS_VALU"]); w=sum(v["SQ_WAVES"])/len(v["SQ_WAVES"])
