@@ -312,6 +312,57 @@ def test_full_size_properties(workload):
             np.testing.assert_array_equal(g.download(Y2, F.LH_VAR_RHOE_INT), g.download(Y, F.LH_VAR_RHOE_INT))
 
 
+def test_full_size_c5_per_column_parameters():
+    """BASELINE config 5 at its per-GPU size: 1e6 columns x 128 levels, per-column van Genuchten
+    parameters and porosity, per-column infiltration flux at the top, free drainage at the bottom.
+    Size-independent properties on EVERY column + sampled parity against the oracle."""
+    import bench
+    import dataclasses
+    N = 1_000_000
+    case = bench.build_case("c5", N, 0)
+    om = case.om
+    n = om.nlev
+    dz = (om.zmax - om.zmin) / n
+    with pc.GpuModel(case) as g:
+        F = g.F
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        g.rhs(Y, Ya, dY)
+        d = g.tendencies(dY)
+        assert g.status() == 0
+        assert np.all(d["ti"] == 0)
+        # the column sum of the tendency telescopes to the two boundary fluxes:
+        # dz sum_i d vl_i = -(F_top - F_bottom), F_top = -0.5 Ksat_c (prescribed),
+        # F_bottom = -K(bottom cell) (free drainage, boundary_conditions.jl:328-356)
+        diag = g.state(0b1111)
+        F.check(g.L.lh_diagnostics(g.ctx, Y, Ya, diag), g.ctx)
+        K0 = np.empty(N)
+        F.check(g.L.lh_download_level(g.ctx, diag, F.LH_DIAG_K, 0, K0.ctypes.data_as(C.c_void_p)), g.ctx)
+        f_top = np.asarray(om.percol_bc[(M.FACE_TOP, M.COMP_HYDROLOGY)], dtype=np.float64)
+        lhs = dz * d["vl"].astype(np.float64).sum(axis=1)
+        rhs = -(f_top - (-K0))
+        scale = dz * np.abs(d["vl"].astype(np.float64)).sum(axis=1) + np.abs(f_top) + np.abs(K0)
+        assert np.max(np.abs(lhs - rhs) / scale) < 64 * n * np.finfo(np.float64).eps
+        # sampled parity: 4096 columns spread over the batch, with their own parameters
+        idx = np.linspace(0, N - 1, 4096).astype(np.int64)
+        sub_om = dataclasses.replace(om, percol={k: v[idx] for k, v in om.percol.items()},
+                                     percol_bc={k: v[idx] for k, v in om.percol_bc.items()})
+        sub = dataclasses.replace(case, om=sub_om, ncols=len(idx), vl=np.ascontiguousarray(case.vl[idx]),
+                                  ti=np.ascontiguousarray(case.ti[idx]))
+        want = pc.run_oracle_rhs(sub, nthreads=8)
+        pc.assert_tendencies_close(sub, {k: v[idx] for k, v in d.items()}, want, 4.0, label="[c5 full size]")
+        # three device steps: every column's water changes by exactly the boundary fluxes' work
+        # to rounding is not a closed form (K_bottom moves); what is: both engines agree bitwise
+        dt = O.stable_dt(sub.om, sub.vl, sub.ti, None, 0.2)
+        F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, dt, 3, None), g.ctx)
+        vl1 = g.download(Y, F.LH_VAR_VARTHETA_L)
+        assert np.all(np.isfinite(vl1)) and np.max(np.abs(vl1 - case.vl)) > 0
+        Y2, _ = g.prognostic_and_aux()
+        F.check(g.L.lh_set_tuning(g.ctx, b"persist=0"), g.ctx)
+        F.check(g.L.lh_step_ssprk33(g.ctx, Y2, Ya, 0.0, dt, 3, None), g.ctx)
+        np.testing.assert_array_equal(g.download(Y2, F.LH_VAR_VARTHETA_L), vl1)
+
+
 def test_stable_dt_matches_oracle_and_device_dt_stepping():
     """lh_stable_dt against the oracle's rule, and adaptive stepping with dt kept in
     device memory (lh_stable_dt_device -> [RCCL min all-reduce] ->
