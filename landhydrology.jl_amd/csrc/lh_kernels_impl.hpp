@@ -23,6 +23,11 @@ namespace lh {
 #define LH_RHS_WAVES_PER_SIMD 8
 #endif
 
+// waves/SIMD the Float32 coupled tendency + step-bound launch is compiled for (86 VGPRs unconstrained)
+#ifndef LH_F32C_DT_WAVES
+#define LH_F32C_DT_WAVES 5
+#endif
+
 // The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
 // per-column / conductivity-factor variants and the libm debug policy keep what
 // they need (a bound there only produces scratch spills).
@@ -48,7 +53,7 @@ constexpr int rhs_waves_per_simd() {
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
     // (the Float32 coupled tendency + step bound needs ~90 VGPRs: held to 72 it spills 18 values
     // per level to scratch and runs 0.34 instead of 0.2x ms on 1e6 x 64)
-    if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? (MODE == 4 ? 5 : 7) : 1;
+    if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? (MODE == 4 ? LH_F32C_DT_WAVES : 7) : 1;
     if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
 }
