@@ -399,13 +399,14 @@ def main():
 
     # HBM bytes per launch from committed PMC passes of this same command line (rocprofv3 cannot
     # run inside the timed process): profiles/pmc_traffic.json, written by tools/gpu_profile.sh
-    traffic, traffic_source, traffic_command, valu_per_cell = None, None, None, None
+    traffic, traffic_source, traffic_command, valu_per_cell, valu_busy = None, None, None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tr = json.load(fh).get(a.workload + ("_nozero" if a.no_known_zero else ""))
         if tr and tr["ncols"] == a.ncols and tr["nlev"] == nlev and tr.get("known_zero", True) != a.no_known_zero:
             traffic, traffic_source, traffic_command = tr["total_bytes"], tr.get("source"), tr.get("command")
             valu_per_cell = tr.get("valu_per_cell")
+            valu_busy = tr.get("valu_busy")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -452,7 +453,11 @@ def main():
                      "fused_dt_kernel_ms": fused_ms,
                      "stream_probe": probe,
                      "kernel_frac_of_stream_probe": (kernel_gbs / probe["gbs"]) if probe and "gbs" in probe else None,
-                     "valu_per_cell": valu_per_cell},
+                     "valu_per_cell": valu_per_cell,
+                     "valu_busy_profiled": valu_busy,
+                     "valu_is": "PROFILED (same committed PMC passes as traffic): VALU instructions per cell-update, and the "
+                                "fraction of the launch the SIMDs spend issuing them (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / "
+                                "GRBM_GUI_ACTIVE per XCD) -- the Float64 kernels are bound by this, not by HBM"},
         "stable_dt_seen": dt_seen,
         "placement_tuning": placement,
     }

@@ -57,6 +57,11 @@ for w in workloads:
         "read_bytes": read_b, "write_bytes": write_b, "total_bytes": read_b + write_b,
         "valu_per_cell": rec["SQ_INSTS_VALU"] * 64.0 / cells,
         "salu_per_cell": rec["SQ_INSTS_SALU"] * 64.0 / cells,
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (a wave64 instruction holds its SIMD for 4 cycles);
+        # GRBM_GUI_ACTIVE is the sum over the 8 XCDs of the cycles the launch was active; 1024 SIMDs
+        "valu_busy": (4.0 * rec["SQ_ACTIVE_INST_VALU"] / (1024.0 * rec["GRBM_GUI_ACTIVE"] / 8.0)
+                      if rec.get("SQ_ACTIVE_INST_VALU") and rec.get("GRBM_GUI_ACTIVE") else None),
+        "gui_active_cycles_per_xcd": rec.get("GRBM_GUI_ACTIVE", 0) / 8.0 or None,
         "kernel": rec["kernel"],
         "source": f"profiles/{rnd}_{w}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, "
                   f"separate passes; FETCH_SIZE x2 gfx950 correction)",

@@ -63,7 +63,8 @@ if bench_line:
 if bench_line and dom:
     rec = {"kernel": dom[:160]}
     for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", "SQ_INSTS_VALU"),
-                     ("pmc_sq", "SQ_INSTS_SALU"), ("pmc_sq", "SQ_WAVES")):
+                     ("pmc_sq", "SQ_INSTS_SALU"), ("pmc_sq", "SQ_WAVES"), ("pmc_sq", "SQ_ACTIVE_INST_VALU"),
+                     ("pmc_grbm", "GRBM_GUI_ACTIVE")):
         v = [float(r["Counter_Value"]) for r in rows(f"{sub}/**/*counter_collection.csv")
              if r.get("Kernel_Name") == dom and r["Counter_Name"] == key]
         if v:
