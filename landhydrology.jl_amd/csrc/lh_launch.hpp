@@ -9,7 +9,10 @@ enum { MATH_FAST = 0, MATH_LIBM = 1 };
 template <int CPL_, int PF_, bool NT_, bool SEG_ = false> struct KCfg;
 // production launch shape per working type (chosen by measurement)
 template <typename FT> struct DefaultCfg;
-template <> struct DefaultCfg<double> { using type = KCfg<1, 2, false>; }; // 2 levels in flight: -2..3 % (profiles/round1_tune_prefetch.txt)
+#ifndef LH_PF64
+#define LH_PF64 2 // levels in flight ahead of the one computed (Float64): -2..3 % against 1 (profiles/round1_tune_prefetch.txt)
+#endif
+template <> struct DefaultCfg<double> { using type = KCfg<1, LH_PF64, false>; };
 template <> struct DefaultCfg<float> { using type = KCfg<2, 1, false>; };
 
 // run-time launch overrides (LH_TUNE environment variable; tuning builds only
