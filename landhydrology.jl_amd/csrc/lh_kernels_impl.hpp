@@ -580,6 +580,11 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 template <int MODEL> constexpr int cs_exchange_arrays() {
     return MODEL == MODEL_COUPLED ? 5 : 2;
 }
+// one-wave columns also publish the flux of the face BELOW each cell (water and/or heat), so that the
+// face above is read, not evaluated a second time
+template <int MODEL> constexpr int cs_flux_arrays() {
+    return MODEL == MODEL_COUPLED ? 2 : 1;
+}
 static inline int cs_fetch_tiles(int model, bool noice, bool need_Taux) {
     if (model == MODEL_RICHARDS) return 1 + (noice ? 0 : 1) + (need_Taux ? 2 : 0); // T sits in tile 3
     return 3; // vl, ti, rhoe (HEAT reads the first two from Ya)
@@ -602,12 +607,15 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const FT dt = dt_device ? *dt_device : dt_value;
     // exchange arrays of this column: (K, h) for the water, (T, kappa) for the heat, rho_e_l K for
     // both -- only what the model needs (LDS per workgroup sets how many workgroups a CU holds)
-    constexpr int NARR = cs_exchange_arrays<MODEL>();
+    constexpr int NARR = cs_exchange_arrays<MODEL>() + (WAVE ? cs_flux_arrays<MODEL>() : 0);
     FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * n;
     FT* sh = sK + n;
     FT* sT = WATER ? sh + n : sK;
     FT* sKap = sT + n;
     FT* sE = sKap + n;
+    // (WAVE) fluxes of the face below cell i: water, then heat
+    FT* sFw = reinterpret_cast<FT*>(s_dyn) + (size_t(slot) * NARR + cs_exchange_arrays<MODEL>()) * n;
+    FT* sFe = WATER ? sFw + n : sFw;
     const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
     DevParams<FT> P = P0; // boundary values change per stage
@@ -712,7 +720,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                         Fw_hi = Fw_b;
                         Fe_hi = Fe_b;
                     }
-                } else {
+                } else if (!WAVE) { // (one-wave columns read the neighbour's flux below instead)
                     FT gh = FT(0);
                     if (WATER) {
                         gh = (sh[i + 1] - h) * P.half_inv_dz;
@@ -723,6 +731,20 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                         Fe_hi = -(kap + sKap[i + 1]) * gT;
                         if (WATER) Fe_hi = Fe_hi - (E + sE[i + 1]) * gh;
                     }
+                }
+            }
+            if (WAVE) {
+                // each interior face is evaluated ONCE, by the cell above it (the expression of
+                // rhs_kernel, lower cell first), and handed down through LDS: the same bits the
+                // two-sided evaluation gives, four (Richards) to ten (coupled) instructions less
+                if (i < n) {
+                    if (WATER) sFw[i] = Fw_lo;
+                    if (HEAT) sFe[i] = Fe_lo;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (i < n - 1) {
+                    if (WATER) Fw_hi = sFw[i + 1];
+                    if (HEAT) Fe_hi = sFe[i + 1];
                 }
             }
             const FT dvl = WATER ? -((Fw_hi - Fw_lo) * P.inv_dz) : FT(0);
@@ -1145,7 +1167,7 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && factors && P.viscosity_kind;
     const int tiles = cs_fetch_tiles(MODEL, noice && !factors, need_Taux);
-    const int narr = cs_exchange_arrays<MODEL>();
+    const int narr = cs_exchange_arrays<MODEL>() + (wave ? cs_flux_arrays<MODEL>() : 0);
     const unsigned dyn = (unsigned)(cpb * (size_t)(narr > tiles ? narr : tiles) * (size_t)P.nlev * sizeof(FT));
     using M = MathFast<FT>;
 #define LH_CS(F, PC, NI)                                                                                          \
