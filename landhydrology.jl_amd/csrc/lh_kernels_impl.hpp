@@ -182,7 +182,9 @@ __device__ __forceinline__ bool finite(FT x) {
 // MODE 0: write the tendency dY (its theta_i plane is not touched: d theta_i = 0, see below).
 // MODE 4: MODE 0 plus the local stable-step bound of the same state (the rule of
 //         stable_dt_kernel, from the K, dpsi/dvl, kappa, rho_c_s this pass has in
-//         registers anyway): one integer atomicMin per wave into P.dt_out.
+//         registers anyway, accumulated in Float32: a Courant-type bound needs seven
+//         digits, and the maximum of non-negative floats is an integer maximum of their
+//         bits): one division and one integer atomicMin per wave into P.dt_out.
 // MODE 1..3: fused SSPRK33 stage s (OrdinaryDiffEq SSPRK33, Shu-Osher form):
 //   1: U1 = Y + dt f(Y)              (in = Y,  out = U1)
 //   2: U1 = (3 Y + U1 + dt f(U1))/4  (in = U1, base = Y, out = U1)
