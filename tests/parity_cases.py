@@ -488,9 +488,19 @@ def closure_tolerances(case: Case, diag, Cw: float):
         w = np.where(S < 1, 1.0 - t, 1.0)
         condK = condK + np.where(S < 1, 2.0 * m * t * np.maximum(w, 1e-300) ** (m - 1.0)
                                  / np.maximum(inner, 1e-300), 0.0)
+        # and S itself is computed (a difference and a quotient: one to two roundings in any
+        # implementation): the same chain amplifies ITS relative error by another 1/m
+        # (d ln t / d ln S), which matters for small m (clay-like n < 1.3) next to saturation
+        condK = condK + np.where(S < 1, 2.0 * t * np.maximum(w, 1e-300) ** (m - 1.0)
+                                 / np.maximum(inner, 1e-300), 0.0)
         u = np.where(Se < 1, Se ** (-1.0 / m) - 1.0, 0.0)
         condpsi = np.where(Se < 1, 1.0 + (u + 1.0) / (n * np.maximum(u, 1e-300)) +
                            np.abs(np.log(np.maximum(Se, 1e-300))) / (m * n), 2.0)
+        # Se itself is a computed quantity (a difference and a quotient, or their logarithms: one
+        # to two roundings in any implementation), and psi amplifies its relative error by
+        # |d ln psi / d ln Se| = (u + 1) / (u n m) -- 1/m times the term above, which only covers a
+        # rounding of S^(-1/m); it matters for small m (clay-like n < 1.3) next to saturation
+        condpsi = condpsi + np.where(Se < 1, (u + 1.0) / (n * m * np.maximum(u, 1e-300)), 0.0)
     # conductivity factors: exp(gamma (T - T_ref)) and 10^(-Omega f_i) are powers too
     cf = om.cf
     if cf.viscosity_kind:
