@@ -140,10 +140,14 @@ __device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<
 // NOICE: the ice plane of the state is known to be all zeros (lh_state zero bits): ti is the
 // literal 0, nu_eff == nu, and the separate psi saturation never exists -- the same numbers as
 // the general path produces for ti == 0, with the ice code compiled out.
-// -psi / q in Float32 (v_cvt_f32_f64 x2, v_rcp_f32, v_mul_f32 with a negated operand)
+// -psi / q in Float32 (v_cvt_f32_f64 x2, v_rcp_f32, v_mul_f32 with a negated operand), kept finite:
+// a bone-dry cell of a clay-like soil has |psi| beyond the Float32 range while its K underflows to 0,
+// and 0 x Inf would poison the column's maximum (the value is non-negative: an integer minimum of the
+// bit patterns clamps Inf -- and a NaN -- to FLT_MAX)
 template <typename FT>
 __device__ __forceinline__ float slope32(FT psi, FT q) {
-    return -float(psi) * __builtin_amdgcn_rcpf(float(q));
+    const float s = -float(psi) * __builtin_amdgcn_rcpf(float(q));
+    return __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(int, s), 0x7f7fffff));
 }
 
 // log2(nu - theta_r) by the math policy's own log2: with it log2 Se = log2 S + (l2_por -

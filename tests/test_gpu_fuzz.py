@@ -21,3 +21,41 @@ def test_randomised_closures_and_tendencies_stay_inside_the_tolerance_model():
     import fuzz_closures
     worst, failed = fuzz_closures.run(nseeds=2, verbose=False)
     assert failed == 0 and worst <= 1.0, (worst, failed)
+
+
+def test_fused_step_bound_survives_values_beyond_the_float32_range():
+    """The fused launch accumulates its step bound in Float32.  A bone-dry clay-like column
+    (n = 1.15) has |psi| ~ 1e60 next to a K that underflows to 0 in Float32: 0 x Inf must not turn
+    into a NaN or a zero step -- the bound is the Float64 sweep's (lh_stable_dt) to Float32 rounding.
+    (Where the rule itself leaves the Float32 range -- a wet cell next to such a dry one gives
+    D = K dpsi/dvl ~ 1e54 -- both routes return a step of practically zero, 0 and 1e-66: not compared.)"""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import case_model as M
+    import parity_cases as pc
+    n, N = 32, 200
+    vg_n = np.full(N, 2.0)
+    vg_n[17] = 1.15
+    om = M.CaseModel(M.MODEL_RICHARDS, n, -1.6, 0.0, bc=pc._flux_bcs(hydrology=0.0),
+                     percol=dict(vg_n=vg_n))
+    nu = om.soil.nu
+    c = np.arange(N)[:, None]
+    vl = nu * (0.3 + 0.5 * pc.uhash(c, np.arange(n)[None, :], 1000))
+    vl[17, :] = 1e-9 * nu                  # the clay-like column: bone dry throughout
+    case = pc.Case("dry_clay", om, np.float64, N, vl=vl, ti=np.zeros((N, n)))
+    psi = pc.O.diagnostics(om, case.vl, case.ti)["psi"]
+    assert np.abs(psi[17, 0]) > 1e45       # beyond the Float32 range
+    with pc.GpuModel(case) as g:
+        F = g.F
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        tdt = torch.full((1,), -1.0, device="cuda", dtype=torch.float64)
+        F.check(g.L.lh_rhs_stable_dt(g.ctx, 0.0, Y, Ya, dY, 0.5, tdt.data_ptr()), g.ctx)
+        sep = C.c_double()
+        F.check(g.L.lh_stable_dt(g.ctx, Y, Ya, 0.5, C.byref(sep)), g.ctx)
+    got = float(tdt.item())
+    assert sep.value > 1e-3                # a sane bound, set by the ordinary columns
+    assert np.isfinite(got) and got > 0 and abs(got - sep.value) <= 1e-6 * sep.value, (got, sep.value)
