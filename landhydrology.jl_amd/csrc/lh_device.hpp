@@ -26,7 +26,7 @@ struct ColC {
     FT log2_alpha;                  // log2(alpha), for the log-domain psi
     FT l2_por;                      // log2(nu - theta_r) BY THE DEVICE'S OWN log2 (finish_colc): ice lanes
     // exponent multipliers of the log-domain closures, pre-scaled by the exp2 unit
-    // of the math policy (MathFast<double>::EXP2_SCALE = 128, else 1)
+    // of the math policy (MathFast<double>::EXP2_SCALE = 2048, else 1)
     FT e_inv_m, e_m, e_inv_n, e_log2_alpha, e_one; // S*/m, S*m, S*/n, S*log2 alpha, S
 };
 
