@@ -27,6 +27,16 @@ namespace lh {
 #ifndef LH_F32C_DT_WAVES
 #define LH_F32C_DT_WAVES 5
 #endif
+// ... and whether that launch keeps its column constants in VGPRs (as the plain tendency launch
+// does) or in SGPRs at LH_F32C_DT_WAVES_SGPR waves/SIMD
+// (measured on C3, fused-dt launch: VGPR constants at 5 waves 0.215 ms; SGPR constants at 8 waves
+// with 12 B of scratch 0.224, at 7 waves 0.222)
+#ifndef LH_F32C_DT_VGPRCONST
+#define LH_F32C_DT_VGPRCONST 1
+#endif
+#ifndef LH_F32C_DT_WAVES_SGPR
+#define LH_F32C_DT_WAVES_SGPR 8
+#endif
 
 // The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
 // per-column / conductivity-factor variants and the libm debug policy keep what
@@ -36,6 +46,7 @@ namespace lh {
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int MODE>
 constexpr bool f32_coupled_vgpr_constants() {
     if (MODEL != MODEL_COUPLED || PERCOL || !M::is_production || !(MODE == 0 || MODE == 4)) return false;
+    if (sizeof(FT) == 4 && MODE == 4) return LH_F32C_DT_VGPRCONST != 0;
     return sizeof(FT) == 8 || !FACTORS; // Float64 (no occupancy bound there): +2.5 % on f3c64
 }
 
@@ -54,7 +65,7 @@ constexpr int rhs_waves_per_simd() {
     // (the Float32 coupled tendency + step bound needs ~90 VGPRs: held to 72 it spills 18 values
     // per level to scratch and runs 0.34 instead of 0.2x ms on 1e6 x 64)
     if (f32_coupled_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, MODE>()) return sizeof(FT) == 4 ? (MODE == 4 ? LH_F32C_DT_WAVES : 7) : 1;
-    if (sizeof(FT) == 4) return LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
+    if (sizeof(FT) == 4) return (MODE == 4 && MODEL == MODEL_COUPLED) ? LH_F32C_DT_WAVES_SGPR : LH_RHS_WAVES_PER_SIMD; // coupled/heat Float32
     return 1;
 }
 
