@@ -1106,7 +1106,8 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
         const int cplv = tune.cpl > 0 ? tune.cpl : CFG::CPL, pfv = tune.pf > 0 ? tune.pf : CFG::PF;
 #define LH_TRY(C, F, N)                                                                            \
     if (cplv == C && pfv == F && ntv == N) {                                                       \
-        launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M, false>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
+        if (noice) launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M, true>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
+        else launch_rhs_mode<FT, MODEL, false, false, KCfg<C, F, N>, M, false>(P, in, aux, base, out, dt, dt_dev, 0, block, s); \
         return;                                                                                    \
     }
         LH_TRY(1, 1, true) LH_TRY(1, 2, true) LH_TRY(1, 3, true) LH_TRY(1, 4, true)
