@@ -199,6 +199,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.kersten_exp_unfrozen = (FT(1) + om - a * q - g) / FT(2); // SoilHeatParameterizations.jl:165
     P.kersten_exp_frozen = FT(1) + om;                         // :171
     P.one_minus_om = FT(1) - om;                               // :169
+    P.neg_b_log2e_sc = FT(-double(P.b) * 1.4426950408889634 * (sizeof(FT) == 8 ? double(EXP_TAB_N) : 1.0));
     P.l2_kappa_sat_unfrozen = FT(std::log2(double(P.kappa_sat_unfrozen)));
     P.l2_kappa_sat_frozen = FT(std::log2(double(P.kappa_sat_frozen)));
     // FT(cp_l(param_set) * _rho_l): Float64 product of the constant and the

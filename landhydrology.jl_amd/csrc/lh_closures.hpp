@@ -299,12 +299,19 @@ __device__ __forceinline__ FT kappa_closure_log(const M& mm, const DevParams<FT>
         K_e = mm.exp2_scaled(mm.log2(S_r) * e_sel);
     }
     if (unfrozen) {
-        const FT e = mm.exp(-P.b * S_r);
+        const FT e = mm.exp2_scaled(S_r * P.neg_b_log2e_sc); // exp(-b S_r): -b log2(e) x the exp2 unit, one product
         const FT a = mm.pow_neg3(FT(1) + e);    // (1 + exp(-b S_r))^(-3)
         const FT h = (FT(1) - S_r) * FT(0.5);
         const FT d = a - h * h * h;             // ((1 - S_r)/2)^3
-        // (.)^(1 - nu_om): the exponent is exactly 1 for soils without organic matter
-        K_e = K_e * ((P.one_minus_om == FT(1)) ? d : mm.pow(d, P.one_minus_om));
+        // (.)^(1 - nu_om): the exponent is exactly 1 for soils without organic matter.  A real
+        // (uniform) branch: the Float32 compiler otherwise evaluates the power for every cell and
+        // selects -- two transcendentals and four more instructions per cell for nothing
+        FT dp = d;
+        if (P.one_minus_om != FT(1)) {
+            dp = mm.pow(d, P.one_minus_om);
+            asm volatile("" : "+v"(dp));
+        }
+        K_e = K_e * dp;
     }
     FT k_sat = P.kappa_sat_unfrozen;            // tl/tw == 1 exactly when ti == 0
     if (!NOICE && ti != FT(0)) {

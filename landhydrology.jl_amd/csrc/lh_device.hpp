@@ -52,6 +52,7 @@ struct DevParams {
     FT kersten_exp_unfrozen; // (1 + nu_om - a*nu_q - nu_g)/2  (SoilHeatParameterizations.jl:165)
     FT kersten_exp_frozen;   // 1 + nu_om                      (:171)
     FT one_minus_om;         // 1 - nu_om                      (:169)
+    FT neg_b_log2e_sc;       // -b log2(e) x the exp2 unit of the production math: exp(-b S_r) as one 2^(.)
     // log2 of the saturated conductivities, for kappa_su^(tl/tw) kappa_sf^(ti/tw) as one 2^(.)
     FT l2_kappa_sat_unfrozen, l2_kappa_sat_frozen;
     // CLIMAParameters constants as SoilHeatParameterizations.jl forms them

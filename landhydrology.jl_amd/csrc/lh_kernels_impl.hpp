@@ -240,7 +240,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
         vr(P.rho_c_ds); vr(P.rhocp_l); vr(P.rhocp_i); vr(P.T_ref); vr(P.kappa_sat_unfrozen);
         vr(P.l2_kappa_sat_unfrozen); vr(P.l2_kappa_sat_frozen); vr(P.kersten_exp_unfrozen);
-        vr(P.kersten_exp_frozen); vr(P.b);
+        vr(P.kersten_exp_frozen); vr(P.neg_b_log2e_sc);
         if (MODE != 4) { // (the step-bound bookkeeping of MODE 4 needs the registers: 175 VGPRs = 2 waves/SIMD otherwise)
             vr(P.rho_i); vr(P.LH_f0); vr(P.inv_dz); vr(P.half_inv_dz);
             if (FACTORS) { vr(P.gamma); vr(P.T_ref_visc); vr(P.Omega); }
