@@ -208,9 +208,9 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         // compiler evaluates it for every cell and selects, six VALU instructions per cell)
         Kb = c.Ksat; // K_r = 1
         if (WANT_PSI && shared) {
-            FT ps = (S == FT(1)) ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
-            asm volatile("" : "+v"(ps));
-            psi = ps;
+            FT vin = vl; // (opaque INPUT: nothing of the saturated evaluation can move above the branch)
+            asm volatile("" : "+v"(vin));
+            psi = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
             if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
@@ -225,9 +225,10 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
         } else {
             const bool one = (same & (S == FT(1))) | (!same & (num == por_e));
-            FT ps = one ? -FT(0) : (vl - nu_eff) * c.inv_S_s;
+            FT vin = vl;
+            asm volatile("" : "+v"(vin));
+            FT ps = one ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
             if (por_e < FT(0)) ps = FT(NAN); // Se < 0: `^` raises DomainError in the reference
-            asm volatile("" : "+v"(ps));
             psi = ps;
             if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
