@@ -486,6 +486,34 @@ def main():
             F.check(L.lh_set_tuning(ctx, b""), ctx)
         except Exception as e:      # noqa: BLE001
             out["ssprk33_error"] = repr(e)
+    if a.stepper:
+        # The adaptive time loop as a host would run it, nothing leaving the device: per step
+        # lh_rhs_stable_dt (tendency + this rank's step bound; with a communicator the library's RCCL
+        # min follows on the same stream) -> lh_step_ssprk33_device_dt (dt read from device memory).
+        # At N > 1 this is the one place the collective sits on the critical path of real stepping.
+        try:
+            def adaptive(nsteps):
+                for _ in range(nsteps):
+                    F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, 0.2, tdt.data_ptr()), ctx)
+                    if not native_comm:
+                        pkg.partition.global_min_dt(tdt)
+                    F.check(L.lh_step_ssprk33_device_dt(ctx, Y, Ya, 0.0, tdt.data_ptr(), None), ctx)
+            adaptive(3)
+            barrier()
+            t1 = time.perf_counter()
+            adaptive(20)
+            barrier()
+            w1 = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([w1], device="cuda", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                w1 = float(tt.item())
+            out["adaptive_ssprk33"] = {"ms_per_step": w1 / 20 * 1e3, "steps": 20, "courant": 0.2,
+                                       "last_dt": float(tdt.item()),
+                                       "is": "lh_rhs_stable_dt (+ min all-reduce over ranks) + lh_step_ssprk33_device_dt "
+                                             "per step, wall clock, max over ranks"}
+        except Exception as e:      # noqa: BLE001
+            out["adaptive_ssprk33_error"] = repr(e)
     if native_comm:
         F.check(L.lh_comm_destroy(ctx), ctx)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
