@@ -300,6 +300,21 @@ int lh_tune_placement(lh_ctx*, lh_state* Y, const lh_state* Ya, lh_state* dY, in
 int lh_step_ssprk33_device_dt(lh_ctx*, lh_state* Y, const lh_state* Ya, double t,
                               const void* dt_device_ft, const double* bc_stage_values);
 
+/* nsteps ADAPTIVE SSPRK33 steps with nothing leaving the device (build-defined: the reference
+ * steps with a fixed user dt, simulation.jl:34-70).  Per step, all on the context's stream:
+ *   f(Y) and the stable-step bound of Y in ONE launch (as lh_rhs_stable_dt; the RCCL min over
+ *   ranks follows when a communicator is attached); dt = min(bound, dt_max) (dt_max <= 0: no
+ *   cap), *elapsed += dt; then stages 2 and 3 -- stage 2 takes (Y, f(Y)) and forms
+ *   U1 = Y + dt f(Y) in registers, so f(Y) is evaluated once, not twice: three evaluations of f
+ *   per step instead of the four of lh_rhs_stable_dt + lh_step_ssprk33_device_dt, and bitwise
+ *   their result.
+ * Boundary values are the constants of lh_set_bc (a time-dependent Dirichlet closure needs the
+ * stage times on the host: use the per-step calls).  dt_device_ft: one FT in device memory,
+ * holds the last step's dt afterwards; elapsed_device_ft: NULL or one FT in device memory that
+ * accumulates the simulated time.  Does not synchronise. */
+int lh_step_ssprk33_adaptive(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double courant,
+                             double dt_max, int64_t nsteps, void* dt_device_ft, void* elapsed_device_ft);
+
 /* Build-defined stable step (the reference uses a fixed user dt):
  * courant*dz^2 / max over owned faces of the face diffusivities
  * ((K_lo+K_hi)/2 * max dpsi/dvl, (kappa_lo+kappa_hi)/2 / min rho_c_s; boundary

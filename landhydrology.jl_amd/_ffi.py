@@ -95,6 +95,7 @@ SIGNATURES = {
     "lh_step_ssprk33": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, _DP]),
     "lh_ssprk33_stage": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, _DP]),
     "lh_step_ssprk33_device_dt": (C.c_int, [_P, _P, _P, C.c_double, _P, _DP]),
+    "lh_step_ssprk33_adaptive": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_int64, _P, _P]),
     "lh_tune_placement": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint32, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float)]),
     "lh_stable_dt": (C.c_int, [_P, _P, _P, C.c_double, _DP]),

@@ -84,6 +84,7 @@ struct lh_ctx {
     double* d_math_tab = nullptr;      // log2/exp2 tables of MathFast<double>
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
     lh_state* scratch_u2 = nullptr;    // second stage state (level-segmented launches cannot update U1 in place)
+    lh_state* scratch_k1 = nullptr;    // f(Y) of lh_step_ssprk33_adaptive
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int math = MATH_FAST;
     Tune tune;
@@ -1085,6 +1086,7 @@ int lh_state_destroy(lh_ctx* c, lh_state* s) {
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch_u1 == s) c->scratch_u1 = nullptr;
     if (c->scratch_u2 == s) c->scratch_u2 = nullptr;
+    if (c->scratch_k1 == s) c->scratch_k1 = nullptr;
     state_free(c, s);
     return LH_OK;
 }
@@ -1363,6 +1365,57 @@ int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double
                                     : do_rhs<float>(c, in, Ya, Y, out, 0.0, stage + 1, ov, dt_device_ft);
         if (rc) return rc;
     }
+    return LH_OK;
+}
+
+int lh_step_ssprk33_adaptive(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double courant, double dt_max,
+                             int64_t nsteps, void* dt_device_ft, void* elapsed_device_ft) {
+    (void)t;
+    if (!c || !dt_device_ft) return fail(c, LH_EINVAL, "lh_step_ssprk33_adaptive: NULL argument");
+    if (nsteps < 0 || !(courant > 0)) return fail(c, LH_EINVAL, "lh_step_ssprk33_adaptive: need nsteps >= 0 and courant > 0");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    const uint32_t pm = prognostic_mask(c->cfg.model);
+    if ((rc = check_state(c, Y, pm, "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    if (!c->scratch_k1 && (rc = state_alloc(c, pm, &c->scratch_k1))) return rc;
+    if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
+    lh_state* K1 = c->scratch_k1;
+    lh_state* U1 = c->scratch_u1;
+    const bool f64 = c->cfg.dtype == LH_F64;
+    // With a prescribed atmosphere the surface fluxes of a stage come from the stage state's top
+    // cells, which MODE 5 never stores: that model takes the four-launch sequence.
+    const bool three = !c->hp.atmos_on;
+    lh_state* U2 = U1;
+    if (!three && (rc = second_stage_state(c, &U2))) return rc;
+    for (int64_t s = 0; s < nsteps; ++s) {
+        // f(Y) and the step bound of Y in one launch; the global minimum with a communicator
+        rc = f64 ? do_rhs<double>(c, Y, Ya, nullptr, K1, courant, 4, nullptr, nullptr, dt_device_ft)
+                 : do_rhs<float>(c, Y, Ya, nullptr, K1, courant, 4, nullptr, nullptr, dt_device_ft);
+        if (rc) return rc;
+        if ((rc = allreduce_min(c, dt_device_ft))) return rc;
+        if (f64) launch_dt_prepare<double>(static_cast<double*>(dt_device_ft), dt_max, static_cast<double*>(elapsed_device_ft), c->stream);
+        else launch_dt_prepare<float>(static_cast<float*>(dt_device_ft), float(dt_max), static_cast<float*>(elapsed_device_ft), c->stream);
+        if (three) {
+            // stage 2 from (Y, k1): U1 = Y + dt k1 formed in registers; then stage 3
+            rc = f64 ? do_rhs<double>(c, K1, Ya, Y, U1, 0.0, 5, nullptr, dt_device_ft)
+                     : do_rhs<float>(c, K1, Ya, Y, U1, 0.0, 5, nullptr, dt_device_ft);
+            if (rc) return rc;
+            rc = f64 ? do_rhs<double>(c, U1, Ya, Y, Y, 0.0, 3, nullptr, dt_device_ft)
+                     : do_rhs<float>(c, U1, Ya, Y, Y, 0.0, 3, nullptr, dt_device_ft);
+            if (rc) return rc;
+        } else {
+            for (int stage = 0; stage < 3; ++stage) {
+                const lh_state* in = stage == 0 ? Y : (stage == 1 ? U1 : U2);
+                lh_state* out = stage == 2 ? Y : (stage == 1 ? U2 : U1);
+                rc = f64 ? do_rhs<double>(c, in, Ya, Y, out, 0.0, stage + 1, nullptr, dt_device_ft)
+                         : do_rhs<float>(c, in, Ya, Y, out, 0.0, stage + 1, nullptr, dt_device_ft);
+                if (rc) return rc;
+            }
+        }
+    }
+    LH_HIP(c, hipGetLastError());
     return LH_OK;
 }
 

@@ -200,6 +200,11 @@ __device__ __forceinline__ bool finite(FT x) {
 //   1: U1 = Y + dt f(Y)              (in = Y,  out = U1)
 //   2: U1 = (3 Y + U1 + dt f(U1))/4  (in = U1, base = Y, out = U1)
 //   3: Y  = (Y + 2 U1 + 2 dt f(U1))/3 (in = U1, base = Y, out = Y)
+// MODE 5: stage 2 of a step whose first stage was NOT stored: in = k1 = f(Y) (a tendency, e.g. the
+//         one lh_rhs_stable_dt left with the step bound), base = Y.  U1 = Y + dt k1 is formed in
+//         registers with MODE 1's expression and used exactly like MODE 2's stored U1:
+//         out = (3 Y + U1 + dt f(U1))/4.  An adaptive step is then MODE 4 + MODE 5 + MODE 3: three
+//         evaluations of f instead of four, bitwise the four-launch sequence.
 // In the fused stages theta_i is read from BASE (= Y) and never written: its
 // tendency is identically zero (right_hand_side.jl:182, :359), so every stage
 // value of theta_i equals Y's.
@@ -299,9 +304,12 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // uniform row pointers (level 0); HEAT reads the prescribed water fields from
     // Ya (right_hand_side.jl:200-201); fused stages read theta_i from BASE
     const int64_t in0 = SEG ? stride * i_first : 0, out0 = SEG ? stride * i_lo : 0;
-    const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0]) + in0;
+    constexpr bool FROM_K1 = (MODE == 5); // the stage state is Y + dt k1, formed on the fly
+    const FT* r_vl = (MODEL == MODEL_HEAT ? AUX.v[0] : (FROM_K1 ? BASE.v[0] : IN.v[0])) + in0;
     const FT* r_ti = NOICE ? nullptr : (MODEL == MODEL_HEAT ? AUX.v[1] : (TEND ? IN.v[1] : BASE.v[1])) + in0;
-    const FT* r_re = HEAT ? IN.v[2] + in0 : nullptr;
+    const FT* r_re = HEAT ? (FROM_K1 ? BASE.v[2] : IN.v[2]) + in0 : nullptr;
+    const FT* r_k1v = (FROM_K1 && WATER) ? IN.v[0] + in0 : nullptr; // k1 = f(Y)
+    const FT* r_k1e = (FROM_K1 && HEAT) ? IN.v[2] + in0 : nullptr;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     const FT* r_Ta = need_Taux ? AUX.v[3] + in0 : nullptr;
     const FT* b_vl = ((MODE == 2 || MODE == 3) && WATER) ? BASE.v[0] + out0 : nullptr;
@@ -332,7 +340,9 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 
     FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
     FT vl_n[PF][CPL], ti_n[PF][CPL], re_n[PF][CPL], Ta_n[PF][CPL]; // PF levels in flight
+    FT kv_n[PF][CPL], ke_n[PF][CPL];               // MODE 5: k1 of those levels
     FT vl_p[CPL], re_p[CPL];                       // previous cell inputs (fused stages)
+    FT yv[CPL], ye[CPL], yv_p[CPL], ye_p[CPL];     // MODE 5: Y of the current / previous cell (the stage's base)
     FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
     FT nf_acc = FT(0); // += 0 * tendency: becomes NaN once any tendency is non-finite
@@ -346,6 +356,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     for (int j = 0; j < CPL; ++j) {
         K_p[j] = h_p[j] = psi_p[j] = T_p[j] = kap_p[j] = E_p[j] = Fw_lo[j] = Fe_lo[j] = FT(0);
         vl_p[j] = re_p[j] = FT(0);
+        yv[j] = ye[j] = yv_p[j] = ye_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
         Ta[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
         dpsi_p[j] = DmaxW[j] = DmaxT[j] = ircs_p[j] = 0.0f;
@@ -357,6 +368,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         if (!NOICE) rload(r_ti, ti_n[slot]);
         if (HEAT) rload(r_re, re_n[slot]);
         if (need_Taux) rload(r_Ta, Ta_n[slot]);
+        if (FROM_K1 && WATER) { rload(r_k1v, kv_n[slot]); r_k1v += stride; }
+        if (FROM_K1 && HEAT) { rload(r_k1e, ke_n[slot]); r_k1e += stride; }
         r_vl += stride;
         if (!NOICE) r_ti += stride;
         if (HEAT) r_re += stride;
@@ -366,7 +379,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     for (int k = 0; k < PF; ++k) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            vl_n[k][j] = ti_n[k][j] = re_n[k][j] = FT(0);
+            vl_n[k][j] = ti_n[k][j] = re_n[k][j] = kv_n[k][j] = ke_n[k][j] = FT(0);
             Ta_n[k][j] = FT(288);
         }
         if (i_first + k < i_end) fetch(k);
@@ -374,7 +387,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 
     // emit the result of the cell the OUT/BASE row pointers address
     auto emit = [&](const FT (&Fw_hi)[CPL], const FT (&Fe_hi)[CPL], const FT (&u_vl)[CPL],
-                    const FT (&u_re)[CPL]) {
+                    const FT (&u_re)[CPL], const FT (&y_vl)[CPL], const FT (&y_re)[CPL]) {
         FT dvl[CPL], dre[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -389,14 +402,15 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             if (WATER) rstore(o_vl, dvl); // (d theta_i = 0: the plane is kept zero by the host side)
             if (HEAT) rstore(o_re, dre);
         } else {
-            auto stage = [&](const FT* brow, FT* orow, const FT (&u)[CPL], const FT (&k)[CPL]) {
+            auto stage = [&](const FT* brow, FT* orow, const FT (&u)[CPL], const FT (&k)[CPL], const FT (&yb)[CPL]) {
                 FT b[CPL], r[CPL];
-                if (MODE != 1) rload(brow, b);
+                if (MODE == 2 || MODE == 3) rload(brow, b);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
+                    if (FROM_K1) b[j] = yb[j]; // (the base was read with the state: no second load)
                     if (MODE == 1)
                         r[j] = u[j] + dt * k[j];
-                    else if (MODE == 2)
+                    else if (MODE == 2 || MODE == 5)
                         r[j] = (FT(3) * b[j] + u[j] + dt * k[j]) * FT(0.25);
                     else {
                         // s / 3 as s*(1/3) plus one residual correction: a bare multiply by
@@ -409,8 +423,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 }
                 rstore(orow, r);
             };
-            if (WATER) stage(b_vl, o_vl, u_vl, dvl);
-            if (HEAT) stage(b_re, o_re, u_re, dre);
+            if (WATER) stage(b_vl, o_vl, u_vl, dvl, y_vl);
+            if (HEAT) stage(b_re, o_re, u_re, dre, y_re);
         }
         if (WATER) {
             o_vl += stride;
@@ -433,6 +447,12 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             ti[j] = NOICE ? FT(0) : ti_n[k][j];
             re[j] = re_n[k][j];
             Ta[j] = Ta_n[k][j];
+            if (FROM_K1) { // U1 = Y + dt k1, MODE 1's expression
+                yv[j] = vl[j];
+                ye[j] = re[j];
+                if (WATER) vl[j] = yv[j] + dt * kv_n[k][j];
+                if (HEAT) re[j] = ye[j] + dt * ke_n[k][j];
+            }
         }
         if (i + PF < i_end) fetch(k); // keep PF levels in flight ahead of the one computed
         const FT z = s_zc[i];
@@ -495,7 +515,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                     if (WATER) Fe[j] = Fe[j] - (E_p[j] + E[j]) * gh;
                 }
             }
-            if (!SEG || i > i_lo) emit(Fw, Fe, vl_p, re_p); // cell i-1 belongs to this segment
+            if (!SEG || i > i_lo) emit(Fw, Fe, vl_p, re_p, yv_p, ye_p); // cell i-1 belongs to this segment
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 Fw_lo[j] = Fw[j];
@@ -506,6 +526,10 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         for (int j = 0; j < CPL; ++j) {
             vl_p[j] = vl[j];
             re_p[j] = re[j];
+            if (FROM_K1) {
+                yv_p[j] = yv[j];
+                ye_p[j] = ye[j];
+            }
             K_p[j] = K[j];
             h_p[j] = h[j];
             psi_p[j] = psi[j];
@@ -535,7 +559,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 }
             }
         }
-        emit(Fw, Fe, vl_p, re_p);
+        emit(Fw, Fe, vl_p, re_p, yv_p, ye_p);
     }
     if (nf_acc != nf_acc) atomicOr(P.status, 1u);
     if (WANT_DT) { // dt = courant dz^2 / (max D over the wave's columns), one atomicMin per wave
@@ -1048,6 +1072,15 @@ __global__ void __launch_bounds__(256) convert_kernel(FT* dst, const double* src
     if (i < n) dst[i] = FT(src[i]);
 }
 
+// one thread: dt = min(dt, dt_max) (dt_max <= 0: no cap), elapsed += dt
+template <typename FT>
+__global__ void dt_prepare_kernel(FT* dt, FT dt_max, FT* elapsed) {
+    FT d = *dt;
+    if (dt_max > FT(0) && d > dt_max) d = dt_max;
+    *dt = d;
+    if (elapsed) *elapsed += d;
+}
+
 template <typename FT>
 __global__ void init_bits_kernel(typename Bits<FT>::type* p) {
     FT inf = FT(INFINITY);
@@ -1068,7 +1101,7 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
     const int mode_k = M::is_production ? mode : 0;
     int kmax = 256;
 #define LH_KMAX(MD) case MD: kmax = rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MD, NOICE && M::is_production>()>(); break;
-    switch (mode_k) { LH_KMAX(0) LH_KMAX(1) LH_KMAX(2) LH_KMAX(3) LH_KMAX(4) }
+    switch (mode_k) { LH_KMAX(0) LH_KMAX(1) LH_KMAX(2) LH_KMAX(3) LH_KMAX(4) LH_KMAX(5) }
 #undef LH_KMAX
     const int block = (block_req > 0 && block_req <= kmax) ? block_req : kmax;
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
@@ -1085,6 +1118,7 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
             case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
             case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
             case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 5: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 5, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
             default: // 4: tendency + stable-step bound; the minimum starts at +inf
                 hipLaunchKernelGGL((init_bits_kernel<FT>), dim3(1), dim3(1), 0, s, reinterpret_cast<typename Bits<FT>::type*>(P.dt_out));
                 hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
@@ -1313,6 +1347,11 @@ void launch_stream_probe(int64_t ncols, int64_t stride, int nlev, int xcd_remap,
 }
 
 template <typename FT>
+void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, hipStream_t s) {
+    hipLaunchKernelGGL((dt_prepare_kernel<FT>), dim3(1), dim3(1), 0, s, dt, dt_max, elapsed);
+}
+
+template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -1343,6 +1382,7 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
     template void launch_atmos_flux<FT>(const DevParams<FT>&, const AtmosParams<FT>&, int64_t, bool,  \
                                         bool, const FT*, const FT*, const FT*, FT*, FT*, hipStream_t); \
     template void launch_fill<FT>(FT*, int64_t, FT, hipStream_t);                                     \
+    template void launch_dt_prepare<FT>(FT*, FT, FT*, hipStream_t);                                   \
     template void launch_convert<FT>(FT*, const double*, int64_t, hipStream_t);
 
 } // namespace lh

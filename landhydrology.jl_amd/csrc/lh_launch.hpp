@@ -31,7 +31,7 @@ struct Tune {
     int zero = 1;    // use the states' known-zero plane bits (0: always read theta_i and store d theta_i = 0)
 };
 
-// mode 0: tendency into `out`; 1..3: fused SSPRK33 stage (see rhs_kernel)
+// mode 0: tendency into `out`; 4: tendency + step bound; 1..3, 5: fused SSPRK33 stages (see rhs_kernel)
 template <typename FT>
 void launch_rhs(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                 const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev, int mode,
@@ -60,6 +60,9 @@ void launch_atmos_flux(const DevParams<FT>& P, const AtmosParams<FT>& A, int64_t
                        const FT* vl, const FT* ti, const FT* third, FT* out_heat, FT* out_water, hipStream_t s);
 template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s);
+// one thread: dt = min(dt, dt_max), elapsed += dt (lh_step_ssprk33_adaptive)
+template <typename FT>
+void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, hipStream_t s);
 template <typename FT>
 void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s);
 

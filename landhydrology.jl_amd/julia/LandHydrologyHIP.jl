@@ -365,6 +365,25 @@ function step_ssprk33_device_dt!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, dt_
 end
 
 """
+    step_ssprk33_adaptive!(ens, Y, Ya, t, courant, nsteps, dt_dev; dt_max = 0.0, elapsed_dev = C_NULL)
+
+`nsteps` adaptive SSPRK33 steps with nothing leaving the device (lh_step_ssprk33_adaptive): per step
+the tendency and the stable-step bound of `Y` in one launch (the RCCL min over ranks follows when a
+communicator is attached), then stages 2 and 3 -- three evaluations of the right-hand side per step,
+bitwise the result of `rhs_stable_dt!` + `step_ssprk33_device_dt!`.  Constant boundary values only.
+`dt_dev` / `elapsed_dev`: one FT each in device memory (last dt; accumulated simulated time).
+"""
+function step_ssprk33_adaptive!(ens::ColumnEnsemble, Y::DeviceState, Ya, t, courant, nsteps, dt_dev::Ptr{Cvoid};
+                                dt_max = 0.0, elapsed_dev::Ptr{Cvoid} = C_NULL)
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    check(ens.ctx, ccall((:lh_step_ssprk33_adaptive, lib), Cint,
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                         ens.ctx, Y.handle, ya, t, courant, dt_max, nsteps, dt_dev, elapsed_dev))
+    return Y
+end
+
+"""
     tune_placement!(ens, Y, Ya, dY = nothing; max_candidates = 0, move_input = true)
 
 Let the library place the state written by `rhs!` (`dY` given) or the SSPRK33 stage state

@@ -192,3 +192,49 @@ def test_bench_two_ranks_over_native_rccl_when_two_gpus_are_visible():
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert "RCCL inside the library" in line["config"]["partition"], line["config"]["partition"]
     assert line["stable_dt_seen"] and line["stable_dt_seen"] > 0
+
+
+@pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_smooth_f64", "c5_percol_f64"])
+def test_adaptive_stepper_is_bitwise_the_per_step_calls(name):
+    """lh_step_ssprk33_adaptive (f(Y) + step bound in one launch, stage 2 formed from (Y, f(Y)) in
+    registers: three evaluations of f per step) against the sequence it replaces, lh_rhs_stable_dt +
+    lh_step_ssprk33_device_dt per step (four): the same dt values, the same state, bit for bit, and
+    the elapsed time it accumulates on the device is the sum of those dt."""
+    import torch
+    case = pc.make_case(name, ncols=None if name != "c5_percol_f64" else 700)
+    tdtype = torch.float64 if case.dtype == np.float64 else torch.float32
+    nsteps, courant = 4, 0.3
+    with pc.GpuModel(case) as g:
+        F, L, ctx = g.F, g.L, g.ctx
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        t = torch.zeros(1, device="cuda", dtype=tdtype)
+        dts = []
+        for _ in range(nsteps):
+            F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, courant, t.data_ptr()), ctx)
+            F.check(L.lh_step_ssprk33_device_dt(ctx, Y, Ya, 0.0, t.data_ptr(), None), ctx)
+            F.check(L.lh_synchronize(ctx), ctx)
+            dts.append(float(t.item()))
+        ref = _state_arrays(g, Y)
+    with pc.GpuModel(case) as g:
+        F, L, ctx = g.F, g.L, g.ctx
+        Y, Ya = g.prognostic_and_aux()
+        t = torch.zeros(1, device="cuda", dtype=tdtype)
+        el = torch.zeros(1, device="cuda", dtype=tdtype)
+        F.check(L.lh_step_ssprk33_adaptive(ctx, Y, Ya, 0.0, courant, 0.0, nsteps, t.data_ptr(), el.data_ptr()), ctx)
+        F.check(L.lh_synchronize(ctx), ctx)
+        got = _state_arrays(g, Y)
+        assert float(t.item()) == dts[-1]
+        acc = np.zeros(1, dtype=case.dtype)
+        for d in dts:
+            acc += case.dtype(d)
+        assert float(el.item()) == float(acc[0])
+        assert g.status() == 0
+        # a cap below the bound is honoured
+        cap = 0.25 * dts[-1]
+        F.check(L.lh_step_ssprk33_adaptive(ctx, Y, Ya, 0.0, courant, cap, 1, t.data_ptr(), None), ctx)
+        F.check(L.lh_synchronize(ctx), ctx)
+        assert float(t.item()) == float(case.dtype(cap))
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), (name, k)
+    assert len(set(dts)) > 1 and all(d > 0 for d in dts)
