@@ -16,6 +16,6 @@ from .soil import (Column, Dirichlet, EarthParameterSet, FieldVector, Float32, F
                    SoilParams, SSPRK33, TemperatureDependentViscosity, VerticalFlux, boundary_fluxes,
                    compute_turbulent_surface_fluxes, coordinates,
                    default_initial_conditions, initialize_states, make_function_space, make_rhs,
-                   make_update_aux, run, stable_dt, step, tune_placement, vanGenuchten)
+                   make_update_aux, run, stable_dt, step, step_adaptive, tune_placement, vanGenuchten)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

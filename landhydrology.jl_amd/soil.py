@@ -826,6 +826,31 @@ def stable_dt(model: SoilModel, Y: "FieldVector", Ya=None, courant: float = 0.5)
     return out.value
 
 
+def step_adaptive(model: SoilModel, Y: "FieldVector", Ya=None, t: float = 0.0, courant: float = 0.5,
+                  nsteps: int = 1, dt_max: float = 0.0):
+    """Build extension: `nsteps` adaptive SSPRK33 steps of `Y` with nothing leaving the device
+    (lh_step_ssprk33_adaptive: per step the tendency and the stable-step bound in one launch, the
+    min over ranks when a communicator is attached, stages 2 and 3 -- three evaluations of the
+    right-hand side per step).  Boundary values are those of time `t` (constant over the call: a
+    time-dependent Dirichlet closure needs the stage times, i.e. `Simulation` with a fixed dt).
+    Returns (simulated time advanced, last dt)."""
+    if _time_dependent(model) or _aux_time_dependent(model, Ya, t, 1.0):
+        raise ValueError("step_adaptive needs boundary values and prescribed profiles that do not depend on time")
+    be = model._backend()
+    L = F.lib()
+    ya = Ya.handle if isinstance(Ya, FieldVector) else None
+    be.set_bcs(model, t)
+    import torch
+    dtype = torch.float64 if np.dtype(model.domain.FT) == np.float64 else torch.float32
+    buf = torch.zeros(2, device="cuda", dtype=dtype)              # [dt, elapsed]
+    F.check(L.lh_step_ssprk33_adaptive(be.ctx, Y.handle, ya, float(t), float(courant), float(dt_max), int(nsteps),
+                                       C.c_void_p(buf.data_ptr()),
+                                       C.c_void_p(buf.data_ptr() + buf.element_size())), be.ctx)
+    F.check(L.lh_synchronize(be.ctx), be.ctx)
+    dt, elapsed = (float(x) for x in buf.cpu())
+    return elapsed, dt
+
+
 # --------------------------------------------------------------- Simulations
 
 

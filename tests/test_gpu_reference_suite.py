@@ -334,3 +334,47 @@ def test_hydrostatic_equilibrium_setup_with_the_exported_helpers(lh):
     bound = 64 * np.finfo(FT).eps * np.max(K) * (np.max(np.abs(psi)) + 1.0 + nu / S_s) / (1.0 / n) ** 2
     assert np.max(np.abs(dY.soil.ϑ_l[0])) <= bound
     model.close()
+
+
+def test_adaptive_stepping_through_the_host_mirror(lh):
+    """Build extension on the reference's Richards equilibrium setup (richards_equation.jl:1-95: a
+    closed column relaxing towards hydrostatic equilibrium): `step_adaptive` advances the ensemble
+    with the step the stability bound allows, conserves every column's water to rounding, moves
+    towards the same equilibrium as the fixed-dt Simulation, and refuses time-dependent boundaries."""
+    FT = np.float64
+    hm = lh.vanGenuchten(FT, n=2.0, α=2.6, Ksat=0.0443 / 3600 / 100, θr=0.0)
+    N = 300
+    domain = lh.Column(FT, zlim=(-1.0, 0.0), nelements=40, ncolumns=N)
+    bc = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0)),
+                         bottom=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0)))
+    model = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                         hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                         boundary_conditions=bc, soil_param_set=lh.SoilParams(FT, ν=0.495, S_s=1e-3),
+                         earth_param_set=lh.EarthParameterSet())
+    c = np.arange(N)[:, None]
+    ic = lambda z, m: {"ϑ_l": 0.2 + 0.2 * (1.0 + z) + 0.05 * pc.uhash(c, 3, 7) + 0.0 * z, "θ_i": 0.0 * z}
+    Y, Ya = lh.initialize_states(model, ic, 0.0)
+    m0 = Y.soil.ϑ_l.sum(axis=1)
+    v0 = Y.soil.ϑ_l.copy()
+    dt1 = lh.stable_dt(model, Y, Ya, courant=0.3)
+    elapsed, dt_last = lh.step_adaptive(model, Y, Ya, t=0.0, courant=0.3, nsteps=50)
+    assert elapsed > 0 and dt_last > 0 and 10 * dt1 < elapsed < 200 * dt1
+    v1 = Y.soil.ϑ_l
+    assert np.max(np.abs(v1.sum(axis=1) - m0) / m0) < 1e-13            # closed column: mass conserved
+    # relaxation: the water moves down (the profile starts wetter at the top than hydrostatic)
+    assert np.all(v1[:, 0] > v0[:, 0]) and np.all(v1[:, -1] < v0[:, -1])
+    # the step is capped when asked
+    _, dt_cap = lh.step_adaptive(model, Y, Ya, t=elapsed, courant=0.3, nsteps=2, dt_max=0.1 * dt_last)
+    assert dt_cap == 0.1 * dt_last
+    # time-dependent boundary values need the stage times on the host: refused
+    bc2 = lh.SoilColumnBC(top=lh.SoilComponentBC(hydrology=lh.Dirichlet(lambda t: 0.3 + 1e-3 * t)),
+                          bottom=lh.SoilComponentBC(hydrology=lh.VerticalFlux(0.0)))
+    model2 = lh.SoilModel(FT, domain=domain, energy_model=lh.PrescribedTemperatureModel(),
+                          hydrology_model=lh.SoilHydrologyModel(FT, hydraulic_model=hm),
+                          boundary_conditions=bc2, soil_param_set=lh.SoilParams(FT, ν=0.495, S_s=1e-3),
+                          earth_param_set=lh.EarthParameterSet())
+    Y2, Ya2 = lh.initialize_states(model2, ic, 0.0)
+    with pytest.raises(ValueError):
+        lh.step_adaptive(model2, Y2, Ya2, nsteps=1)
+    model.close()
+    model2.close()
