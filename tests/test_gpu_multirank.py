@@ -194,7 +194,8 @@ def test_bench_two_ranks_over_native_rccl_when_two_gpus_are_visible():
     assert line["stable_dt_seen"] and line["stable_dt_seen"] > 0
 
 
-@pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_smooth_f64", "c5_percol_f64"])
+@pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_smooth_f64", "c5_percol_f64",
+                                  "heat_dirichlet_f64", "richards_viscosity_f64", "mixed_smooth_f32", "single_cell_f64"])
 def test_adaptive_stepper_is_bitwise_the_per_step_calls(name):
     """lh_step_ssprk33_adaptive (f(Y) + step bound in one launch, stage 2 formed from (Y, f(Y)) in
     registers: three evaluations of f per step) against the sequence it replaces, lh_rhs_stable_dt +
@@ -237,4 +238,4 @@ def test_adaptive_stepper_is_bitwise_the_per_step_calls(name):
         assert float(t.item()) == float(case.dtype(cap))
     for k in ref:
         assert np.array_equal(ref[k], got[k]), (name, k)
-    assert len(set(dts)) > 1 and all(d > 0 for d in dts)
+    assert all(d > 0 for d in dts)     # (a heat-only column with prescribed water has a constant bound)
