@@ -239,3 +239,27 @@ def test_adaptive_stepper_is_bitwise_the_per_step_calls(name):
     for k in ref:
         assert np.array_equal(ref[k], got[k]), (name, k)
     assert all(d > 0 for d in dts)     # (a heat-only column with prescribed water has a constant bound)
+
+
+def test_adaptive_stepper_is_bitwise_the_per_step_calls_at_full_size():
+    """The same identity on BASELINE config 2 at its full size (1e6 columns: the one-lane-per-column
+    launches, not the level-segmented ones of the small cases above)."""
+    import torch
+
+    import bench
+    case = bench.build_case("c2", 1_000_000, 0)
+    with pc.GpuModel(case) as g:
+        F, L, ctx = g.F, g.L, g.ctx
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        t = torch.zeros(1, device="cuda", dtype=torch.float64)
+        for _ in range(2):
+            F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, 0.3, t.data_ptr()), ctx)
+            F.check(L.lh_step_ssprk33_device_dt(ctx, Y, Ya, 0.0, t.data_ptr(), None), ctx)
+        ref = g.download(Y, F.LH_VAR_VARTHETA_L)
+        dt_ref = float(t.item())
+        Y2, _ = g.prognostic_and_aux()
+        F.check(L.lh_step_ssprk33_adaptive(ctx, Y2, Ya, 0.0, 0.3, 0.0, 2, t.data_ptr(), None), ctx)
+        got = g.download(Y2, F.LH_VAR_VARTHETA_L)
+        assert float(t.item()) == dt_ref and dt_ref > 0
+    assert np.array_equal(ref, got) and np.max(np.abs(ref - case.vl)) > 0
