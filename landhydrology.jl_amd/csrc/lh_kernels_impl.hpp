@@ -57,6 +57,15 @@ constexpr bool heat_vgpr_constants() {
 
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false>
 constexpr int rhs_waves_per_simd() {
+    // Float64 heat kernels with conductivity factors: 127 VGPRs (4 waves/SIMD, 512-thread workgroups)
+    // with the uniform constants left to the SGPR file and its spills beats 156 VGPRs with the
+    // constants VGPR-resident at 3 waves (f3c64 tendency 0.530 vs 0.554 ms); the step-bound launch
+    // would spill to scratch under that bound and keeps the other arrangement
+#ifndef LH_F64_FACTORS_STAGE_WAVES4
+#define LH_F64_FACTORS_STAGE_WAVES4 0
+#endif
+    if (M::is_production && FACTORS && sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && !PERCOL &&
+        (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return 4;
     if (!M::is_production || FACTORS) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? 6 : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
     if (PERCOL) return 1;
@@ -241,7 +250,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // excess to VGPR lanes and reloads them with v_readlane in front of every use (20 VALU
     // instructions per cell).  The constants of the heat closures held in VGPRs instead remove that.
     DevParams<FT> P = P0;
-    if constexpr (heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() && TEND_MODE) {
+    if constexpr (heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() && TEND_MODE && (!FACTORS || PERCOL || MODE == 4)) {
         auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
         vr(P.rho_c_ds); vr(P.rhocp_l); vr(P.rhocp_i); vr(P.T_ref); vr(P.kappa_sat_unfrozen);
         vr(P.l2_kappa_sat_unfrozen); vr(P.l2_kappa_sat_frozen); vr(P.kersten_exp_unfrozen);
