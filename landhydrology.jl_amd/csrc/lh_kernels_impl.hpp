@@ -61,6 +61,8 @@ constexpr int rhs_waves_per_simd() {
     // with the uniform constants left to the SGPR file and its spills beats 156 VGPRs with the
     // constants VGPR-resident at 3 waves (f3c64 tendency 0.530 vs 0.554 ms); the step-bound launch
     // would spill to scratch under that bound and keeps the other arrangement
+    // (Richards with a conductivity factor: 66 VGPRs unconstrained = 6 waves; bounded to 64 for 8 waves it
+    // spills SGPRs to lanes and 12 B to scratch: 0.324 vs 0.307 ms on f3v64 -- left unconstrained)
 #ifndef LH_F64_FACTORS_STAGE_WAVES4
 #define LH_F64_FACTORS_STAGE_WAVES4 0
 #endif
