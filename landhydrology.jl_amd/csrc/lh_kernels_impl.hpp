@@ -38,6 +38,12 @@ namespace lh {
 #define LH_F32C_DT_WAVES_SGPR 8
 #endif
 
+// waves/SIMD of the per-column Richards tendency + step-bound launch (C5); measured: 6 waves (72 VGPRs)
+// 0.511 ms, 8 waves (64 VGPRs + 20 B of scratch) 0.537 ms
+#ifndef LH_PERCOL_DT_WAVES
+#define LH_PERCOL_DT_WAVES 6
+#endif
+
 // The plain production kernels are held to 64 VGPRs (8 waves/SIMD); the
 // per-column / conductivity-factor variants and the libm debug policy keep what
 // they need (a bound there only produces scratch spills).
@@ -69,7 +75,7 @@ constexpr int rhs_waves_per_simd() {
     if (M::is_production && FACTORS && sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && !PERCOL &&
         (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return 4;
     if (!M::is_production || FACTORS) return 1;
-    if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? 6 : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
+    if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? LH_PERCOL_DT_WAVES : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
     if (PERCOL) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE) return LH_RHS_WAVES_PER_SIMD; // no ice ring: fits 64 VGPRs in every mode
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
