@@ -4,6 +4,7 @@
 #include "../../include/landhydro.h"
 #include "lh_launch.hpp"
 #include "lh_fastmath.hpp"
+#include "lh_closures.hpp"
 
 #include <rccl/rccl.h>
 
@@ -76,6 +77,7 @@ struct lh_ctx {
     HostParams hp;
     void* d_zc = nullptr;              // FT[nlev]
     void* d_pc[LH_PC_COUNT] = {};      // FT[ncols] or null
+    double pc_lo[LH_PC_COUNT] = {}, pc_hi[LH_PC_COUNT] = {}; // range of each per-column array (NaN if it holds a NaN)
     void* d_bc_pc[2][2] = {};          // FT[ncols] or null
     uint32_t* d_status = nullptr;
     void* d_dt = nullptr;              // FT scratch for lh_stable_dt
@@ -167,6 +169,8 @@ int segment_length(const lh_ctx* c) {
     return len < nlev ? len : 0;
 }
 
+bool vg_fast_all(const lh_ctx* c);
+
 template <typename FT>
 DevParams<FT> make_params(const lh_ctx* c) {
     const HostParams& h = c->hp;
@@ -233,6 +237,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_S_s = FT(1) / u.S_s;
     u.inv_nu = FT(1) / u.nu;
     u.log2_alpha = FT(std::log2(double(P.vg_alpha)));
+    set_fast_vg(u, P.vg_alpha);
     u.l2_por = FT(0); // filled on the device by finish_colc (the device math policy's own log2)
     {   // exponent multipliers in the exp2 unit of the production math (lh_fastmath.hpp)
         const FT sc = sizeof(FT) == 8 ? FT(MathFast<double>::EXP2_SCALE) : FT(1);
@@ -265,6 +270,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.xcd_remap = 0;
     P.seg_len = segment_length(c);
     P.cs_cpb = c->tune.cpb;
+    P.vg_fast_all = (c->tune.vgfast != 0 && vg_fast_all(c)) ? 1 : 0;
     return P;
 }
 
@@ -312,6 +318,7 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "place_mem=")) && sscanf(q + 10, "%d", &v) == 1 && v >= 1 && v <= 90) tu.place_mem = v;
     if ((q = strstr(t, "zero=")) && sscanf(q + 5, "%d", &v) == 1 && (v == 0 || v == 1)) tu.zero = v;
     if ((q = strstr(t, "xcd=")) && sscanf(q + 4, "%d", &v) == 1 && (v == 0 || v == 1)) tu.xcd = v;
+    if ((q = strstr(t, "vgfast=")) && sscanf(q + 7, "%d", &v) == 1 && (v == 0 || v == 1)) tu.vgfast = v;
     if ((q = strstr(t, "block=")) && sscanf(q + 6, "%d", &v) == 1 && v >= 64 && v <= 1024 && v % 64 == 0) tu.block = v;
     if ((q = strstr(t, "cpl=")) && sscanf(q + 4, "%d", &v) == 1) tu.cpl = v;
     if ((q = strstr(t, "pf=")) && sscanf(q + 3, "%d", &v) == 1) tu.pf = v;
@@ -320,6 +327,23 @@ void parse_tune(Tune& tu, const char* t) {
     if ((q = strstr(t, "rowpad=")) && sscanf(q + 7, "%d", &v) == 1 && v >= 0 && v % 2 == 0) tu.rowpad = v;
     for (q = strstr(t, "pad="); q; q = strstr(q + 4, "pad=")) // not the tail of "rowpad="
         if ((q == t || q[-1] == ',' || q[-1] == ' ') && sscanf(q + 4, "%d", &v) == 1 && v >= 0 && v % 256 == 0) tu.pad = v;
+}
+
+// Whether EVERY column may take the integer-exponent 2^(.) in its water closures (ColC::vg_fast): decided
+// on the host from the scalar parameters and the ranges of the per-column arrays, conservatively (an
+// interval test; every comparison is false for a NaN), because the choice selects the kernel
+// instantiation (rhs_kernel VGF).
+bool vg_fast_all(const lh_ctx* c) {
+    const HostParams& h = c->hp;
+    auto lo = [&](int id, double scalar) { return c->d_pc[id] ? c->pc_lo[id] : scalar; };
+    auto hi = [&](int id, double scalar) { return c->d_pc[id] ? c->pc_hi[id] : scalar; };
+    const double n_lo = lo(LH_PC_VG_N, h.vg.n), n_hi = hi(LH_PC_VG_N, h.vg.n);
+    const double a_lo = lo(LH_PC_VG_ALPHA, h.vg.alpha), a_hi = hi(LH_PC_VG_ALPHA, h.vg.alpha);
+    const double t_lo = lo(LH_PC_VG_THETA_R, h.vg.theta_r), t_hi = hi(LH_PC_VG_THETA_R, h.vg.theta_r);
+    const double nu_lo = lo(LH_PC_NU, h.soil.nu), nu_hi = hi(LH_PC_NU, h.soil.nu);
+    const double m_lo = 1.0 - 1.0 / n_lo; // (Float32 rounding of the parameters moves m by 1e-7: the margin below covers it)
+    return n_lo > 1.0 && n_hi < 1e30 && m_lo >= LH_VG_FAST_MIN_M * 1.001 && a_lo > 1.01e-20 && a_hi < 0.99e20 &&
+           nu_lo - t_hi >= 1.01e-5 && nu_hi - t_lo <= 1.0;
 }
 
 bool any_percol(const lh_ctx* c) {
@@ -862,7 +886,16 @@ int lh_create(lh_ctx** out, const lh_config* cfg) {
             tab[2 * i] = double(1.0L / cc);
             tab[2 * i + 1] = double(log2l(cc));
         }
-        for (int j = 0; j < EXP_TAB_N; ++j) tab[2 * LOG_TAB_N + j] = double(exp2l((long double)j / EXP_TAB_N));
+        for (int j = 0; j < EXP_TAB_N; ++j) {
+            // 2^(j/2048), stored with (j << 9) subtracted from its high word: the kernels put the
+            // binary exponent in place by ONE integer addition of (k << 9), k = 2048 e + j
+            // (MathFast<double>::exp2_scaled_ins); the low word is the value's own
+            const double v = double(exp2l((long double)j / EXP_TAB_N));
+            uint64_t bits;
+            memcpy(&bits, &v, 8);
+            bits -= uint64_t(uint32_t(j) << 9) << 32;
+            memcpy(&tab[2 * LOG_TAB_N + j], &bits, 8);
+        }
         CREATE_HIP(hipMalloc(&c->d_math_tab, tab.size() * sizeof(double)));
         CREATE_HIP(hipMemcpy(c->d_math_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -937,6 +970,18 @@ int lh_set_percol_param(lh_ctx* c, int32_t id, const double* host) {
     if (!c) return LH_EINVAL;
     if (id < 0 || id >= LH_PC_COUNT) return fail(c, LH_EINVAL, "lh_set_percol_param: unknown parameter id %d", id);
     (void)hipSetDevice(c->device);
+    if (host) { // the array's range decides which closure form the ensemble may take (vg_fast_all)
+        double lo = host[0], hi = host[0];
+        bool nan = false;
+        for (int64_t k = 0; k < c->cfg.ncols; ++k) {
+            const double v = host[k];
+            nan = nan || v != v;
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        c->pc_lo[id] = nan ? NAN : lo;
+        c->pc_hi[id] = nan ? NAN : hi;
+    }
     return upload_percol(c, &c->d_pc[id], host);
 }
 

@@ -21,6 +21,19 @@ __host__ __device__ inline void set_scaled_exponents(ColC<FT>& c, FT scale) {
     c.e_log2_alpha = scale * c.log2_alpha;
 }
 
+// ColC::vg_fast: every power the water closures form for this column stays a normal Float64 number,
+// so 2^(.) may put its exponent in place by integer addition (MathFast<double>::exp2_scaled_ins):
+// |log2 S| <= 52 + |log2(nu - theta_r)| <= 69, S^(1/m) >= 2^(-69/0.07) = 2^-986, and psi's exponent
+// (log2 w - log2 S / m) / n - log2 alpha <= 986 / 1.075 + 67 < 1023.
+template <typename FT>
+__host__ __device__ inline void set_fast_vg(ColC<FT>& c, FT alpha) {
+    const FT por = c.nu - c.theta_r;
+    // (every comparison false for NaN parameters: those columns take the v_ldexp form too)
+    c.vg_fast = (c.m >= FT(LH_VG_FAST_MIN_M) && c.m < FT(1) && por >= FT(1e-5) && por <= FT(1) &&
+                 alpha > FT(1e-20) && alpha < FT(1e20)) ? 1 : 0;
+    c.pad_ = 0;
+}
+
 // A non-positive saturation (nu <= theta_r) makes `^` raise DomainError in the
 // reference; here the column's K and psi become NaN (and the status flag is set)
 template <typename FT>
@@ -61,6 +74,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.inv_S_s = FT(1) / c.S_s;
     c.inv_nu = FT(1) / c.nu;
     c.log2_alpha = MathLibm<FT>::log2(alpha);
+    set_fast_vg(c, alpha);
     set_scaled_exponents(c, FT(M::EXP2_SCALE));
     poison_invalid(c);
     // k_dry, SoilHeatParameterizations.jl:268-270, 280-294
@@ -164,16 +178,30 @@ __device__ __forceinline__ bool wave_all(bool pred) {
     return __builtin_amdgcn_ballot_w64(!pred) == 0ull;
 }
 
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
+// RELK: K is returned WITHOUT the factor Ksat (relative conductivity times the conductivity factors);
+// the column kernels fold Ksat into the per-column flux constant instead of multiplying every cell.
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                                   FT& psi, float* dpsi = nullptr) {
+                                                   FT& psi, float* dpsi = nullptr, bool vgfast = false) {
     constexpr FT SC = FT(M::EXP2_SCALE);
     const FT nu_eff = NOICE ? c.nu : c.nu - ti;
-    // max(vl, theta_r + eps), NaN kept (a compare and two 32-bit selects; v_max + a NaN put back
-    // by 0 * vl costs the same once the canonicalising v_max or the asm hazard nop is counted)
-    const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
-    const FT num = vls - c.theta_r;
+    // max(vl, theta_r + eps), NaN kept.  Float64: a bone-dry cell is rare, so the clamp is a real
+    // (wave-level) branch -- one compare per cell on the hot path instead of a compare and two
+    // selects; the empty asm keeps the compiler from turning it back into selects.
+    // (the clamped lanes' difference (theta_r + eps) - theta_r is the column constant the reference's
+    // own subtraction gives: nothing but `num` depends on the clamped value)
+    FT num;
+    if constexpr (M::uses_tables) {
+        num = vl - c.theta_r;
+        if (__builtin_amdgcn_ballot_w64(vl <= c.theta_lim) != 0ull) {
+            num = (vl <= c.theta_lim) ? c.theta_lim - c.theta_r : num;
+            asm volatile("" : "+v"(num));
+        }
+    } else {
+        const FT vls = !(vl <= c.theta_lim) ? vl : c.theta_lim;
+        num = vls - c.theta_r;
+    }
     const FT S = num * c.inv_por;
     const bool same = NOICE || (nu_eff == c.nu); // no ice: the two saturations coincide bitwise
     const bool unsat = S < FT(1);
@@ -187,6 +215,12 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     // wave run both chains one after the other.  Per-lane results do not depend on the choice
     // (see finish_colc), so they do not depend on which cells share a wave either.
     const bool shared = NOICE || wave_all(same);
+    // (Float64 production math) vgfast: the host found every column's powers safely inside the normal
+    // range (ColC::vg_fast), so each 2^(.) puts its exponent in place by integer addition
+    // (exp2_scaled_ins) -- bitwise the v_ldexp form whenever that one's result is a normal number, so
+    // the two psi chains below still agree bit for bit on a lane without ice.
+    bool ins = false;
+    if constexpr (M::uses_tables) ins = vgfast;
 
     // exponents are formed in the exp2 unit of the policy (c.e_* carry the scale)
     FT L = FT(0);   // log2 S of an unsaturated cell (0 otherwise: K_r = 1, and sqrt(S) = 2^0 below)
@@ -194,19 +228,25 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     if (unsat) {
         L = mm.log2(S);
         const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
-        const FT w = FT(1) - mm.exp2_scaled(a);
+        auto ex2 = [&](FT u) -> FT {
+            if constexpr (M::uses_tables) {
+                if (ins) return mm.exp2_scaled_ins(u);
+            }
+            return mm.exp2_scaled(u);
+        };
+        const FT w = FT(1) - ex2(a);
         const FT Lw = mm.log2(w);
-        const FT inner = FT(1) - mm.exp2_scaled(c.e_m * Lw);
-        if (FACTORS) Kb = (inner * inner) * c.Ksat;
-        else Kb = (mm.sqrt(S) * (inner * inner)) * c.Ksat;
+        const FT inner = FT(1) - ex2(c.e_m * Lw);
+        Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner);
+        if (!RELK) Kb = Kb * c.Ksat;
         if (WANT_PSI && shared) {
-            psi = -mm.exp2_scaled(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
+            psi = -ex2(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
         }
     } else {
         // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
         // compiler evaluates it for every cell and selects, six VALU instructions per cell)
-        Kb = c.Ksat; // K_r = 1
+        Kb = RELK ? FT(1) : c.Ksat; // K_r = 1
         if (WANT_PSI && shared) {
             FT vin = vl; // (opaque INPUT: nothing of the saturated evaluation can move above the branch)
             asm volatile("" : "+v"(vin));
@@ -217,11 +257,17 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     if (!NOICE && WANT_PSI && !shared) { // ice somewhere in the wave: psi from every lane's own saturation
         if (unsat_e) {
             // (unsat_e without unsat needs theta_i < 0: out of contract, L is 0 there)
+            auto ex2 = [&](FT u) -> FT {
+                if constexpr (M::uses_tables) {
+                    if (ins) return mm.exp2_scaled_ins(u);
+                }
+                return mm.exp2_scaled(u);
+            };
             const FT Le = L + (c.l2_por - mm.log2(por_e)); // log2 Se; == L bitwise for a lane without ice
             const FT ae = Le * c.e_inv_m;
-            const FT we = FT(1) - mm.exp2_scaled(ae);
+            const FT we = FT(1) - ex2(ae);
             const FT Lwe = mm.log2(we);
-            psi = -mm.exp2_scaled(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
+            psi = -ex2(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
         } else {
             const bool one = (same & (S == FT(1))) | (!same & (num == por_e));
@@ -249,12 +295,13 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false>
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
-                                               FT& psi, float* dpsi = nullptr) {
+                                               FT& psi, float* dpsi = nullptr, bool vgfast = false) {
+    static_assert(!RELK || M::is_production, "the relative-conductivity form exists for the production math only");
     if (M::is_production) {
-        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE>(mm, P, c, vl, ti, T, K, psi, dpsi);
+        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE, RELK>(mm, P, c, vl, ti, T, K, psi, dpsi, vgfast);
     } else {
         water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
         if (WANT_DPSI) { // as the oracle writes it
@@ -380,7 +427,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
                                                 const ColC<FT>& c, int face, int64_t col, FT vl_c,
                                                 FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
                                                 FT& f_w, FT* K_face = nullptr,
-                                                FT* kappa_face = nullptr) {
+                                                FT* kappa_face = nullptr, bool vgfast = false) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     const int ke = P.bc_kind[face][COMP_ENERGY];
@@ -413,7 +460,7 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
             f_w = -K_c;
         } else if (kh == BC_DIRICHLET) { // :371-401
             FT K_f, psi_f;
-            water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f);
+            water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f, nullptr, vgfast);
             if (K_face) *K_face = K_f;
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
                 f_w = K_f * (psi_f - psi_c - dzb) / dzb;

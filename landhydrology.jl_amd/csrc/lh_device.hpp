@@ -28,7 +28,14 @@ struct ColC {
     // exponent multipliers of the log-domain closures, pre-scaled by the exp2 unit
     // of the math policy (MathFast<double>::EXP2_SCALE = 2048, else 1)
     FT e_inv_m, e_m, e_inv_n, e_log2_alpha, e_one; // S*/m, S*m, S*/n, S*log2 alpha, S
+    // every power of the water closures stays a normal number for every S >= eps / (nu - theta_r)
+    // (set_fast_vg): m >= LH_VG_FAST_MIN_M and moderate alpha, porosity.  Clay-like columns below that
+    // (n < 1.075) take the v_ldexp form of 2^(.), which saturates like the reference's pows do.
+    int32_t vg_fast;
+    int32_t pad_;
 };
+// smallest m = 1 - 1/n for which S^(1/m) of the driest representable cell stays a normal number
+#define LH_VG_FAST_MIN_M 0.07
 
 // Everything a launch needs, already rounded to the working type FT the way the
 // Julia constructors round (FT(x)); passed by value as the kernel argument.
@@ -77,6 +84,7 @@ struct DevParams {
     int32_t cs_cpb;         // persistent column stepper: columns per workgroup (0 = launcher's choice)
     int32_t seg_len;        // > 0: level-segmented launch, levels per segment (small ensembles)
     int32_t xcd_remap;      // workgroup -> column-block map that gives each XCD one contiguous column range
+    int32_t vg_fast_all;    // every column has ColC::vg_fast (host decision: uniform parameters + the ranges of the per-column arrays)
 };
 
 // PrescribedAtmosForcing{FT} (boundary_conditions.jl:119-132) plus every constant

@@ -60,6 +60,7 @@ template <> struct MathLibm<double> {
     static __device__ __forceinline__ double exp2_scaled(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sqrt_mul(double x, double f) { return ::sqrt(x) * f; }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_neg3(double x) { return ::pow(x, -3.0); }
 };
@@ -75,6 +76,7 @@ template <> struct MathLibm<float> {
     static __device__ __forceinline__ float exp2_scaled(float x) { return ::exp2f(x); }
     static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float sqrt_mul(float x, float f) { return ::sqrtf(x) * f; }
     static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
     static __device__ __forceinline__ float pow_neg3(float x) { return ::powf(x, -3.0f); }
 };
@@ -126,6 +128,10 @@ template <> struct MathFast<double> {
         return __builtin_fma(r, p, (double)e + l2c);
     }
 
+    // The exp2 table is stored BIASED: entry j holds 2^(j/2048) with (j << 9) subtracted from its
+    // high word, so that adding (k << 9) = (e << 20) + (j << 9) for k = 2048 e + j puts the binary
+    // exponent e in place with ONE 32-bit v_lshl_add_u32 (exp2_scaled_ins); the general form below
+    // adds back (j << 9) = (byte offset << 6) and scales with v_ldexp_f64.
     // 2^(u/2048) for |u| < 2^50 (v_ldexp saturates to 0 / inf far inside that; the
     // closures' exponents are bounded by ~53 n/(n-1)); NaN in, NaN out.
     // k = rint(u) by the shifter trick (the low word of u + 1.5*2^52 is k), u - k in
@@ -136,13 +142,28 @@ template <> struct MathFast<double> {
         const int k = __double2loint(sh);
         const double r = u - (sh - shiftv);                      // exact
         const unsigned off = ((unsigned)k << 3) & ((EXP_TAB_N - 1) << 3);
-        const double tj = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
+        const double tb_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
+        const double tj = __hiloint2double(__double2hiint(tb_) + (int)(off << 6), __double2loint(tb_));
         const int e = k >> EXP_TAB_BITS;
         // 2^(r/2048) - 1 = r (q1 + r (q2 + r q3))
         double p = __builtin_fma(r, 6.461528679825916e-12, q2v);
         p = __builtin_fma(p, r, 0.0003384507717577858);
         const double res = __builtin_fma(tj, r * p, tj);
         return __builtin_amdgcn_ldexp(res, e);
+    }
+    // The same value when the caller GUARANTEES a normal result (|u / 2048| < 1021, u not NaN --
+    // the exponent is inserted by integer addition: no saturation, no NaN propagation through it;
+    // a NaN u still gives NaN because r = u - k is NaN): seven f64 and three 32-bit instructions.
+    __device__ __forceinline__ double exp2_scaled_ins(double u) const {
+        const double sh = u + shiftv;
+        const int k = __double2loint(sh);
+        const double r = u - (sh - shiftv);                      // exact
+        const unsigned off = ((unsigned)k << 3) & ((EXP_TAB_N - 1) << 3);
+        const double tb_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
+        const double T = __hiloint2double(__double2hiint(tb_) + (int)((unsigned)k << 9), __double2loint(tb_)); // 2^(j/2048) 2^e
+        double p = __builtin_fma(r, 6.461528679825916e-12, q2v);
+        p = __builtin_fma(p, r, 0.0003384507717577858);
+        return __builtin_fma(T, r * p, T);
     }
     __device__ __forceinline__ double exp2_core(double t) const { return exp2_scaled(t * EXP2_SCALE); }
 
@@ -178,6 +199,17 @@ template <> struct MathFast<double> {
         const double d = __builtin_fma(-g, g, x);
         return __builtin_fma(d, h, g);
     }
+    // f sqrt(x) for a positive normal x: with y = rsq(x) (relative error < 2^-22), g = x y and
+    // e = 1 - g y, sqrt(x) = g (1 + e/2 + 3 e^2/8 + O(e^3)); the correction is applied to the
+    // product f g directly -- six instructions behind the seed, one less than sqrt() and a product
+    static __device__ __forceinline__ double sqrt_mul(double x, double f) {
+        const double y = __builtin_amdgcn_rsq(x);
+        const double g = x * y;
+        const double e = __builtin_fma(-g, y, 1.0);
+        const double q = __builtin_fma(e, 0.375, 0.5);
+        const double fg = f * g;
+        return __builtin_fma(fg, q * e, fg);
+    }
     // 1/x by v_rcp_f64 and two Newton steps: < 1 ulp for normal x, no
     // div_scale/div_fixup (the closures only take reciprocals of normal values)
     static __device__ __forceinline__ double rcp(double x) {
@@ -212,6 +244,7 @@ template <> struct MathFast<float> {
         return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
     }
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float sqrt_mul(float x, float f) { return __builtin_amdgcn_sqrtf(x) * f; }
     // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division sequence
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float pow_neg3(float x) {

@@ -102,6 +102,12 @@ constexpr int rhs_min_waves() {
     return WAVES >= 8 ? 8 : (WAVES >= 6 ? 6 : (WAVES >= 4 ? 4 : (WAVES >= 2 ? 2 : 1)));
 }
 
+// trips of the level loop (PF levels each) the compiler is told to unroll (0: its own choice)
+#ifndef LH_RHS_OUTER_UNROLL
+#define LH_RHS_OUTER_UNROLL 0
+#endif
+constexpr int RHS_OUTER_UNROLL = LH_RHS_OUTER_UNROLL;
+
 // ----------------------------------------------------------------- helpers
 
 // native clang vectors (the nontemporal builtins do not take HIP_vector_type)
@@ -245,7 +251,10 @@ __device__ __forceinline__ bool finite(FT x) {
 // same numbers the general kernel produces for ti == 0.
 // d theta_i = 0 (right_hand_side.jl:182, :359) is never stored by any mode: the host side keeps
 // the theta_i plane of a tendency state zero (cleared once, tracked by the state's zero bits).
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false>
+// VGF (Float64 production math): every column of the context has m = 1 - 1/n >= LH_VG_FAST_MIN_M, so the
+// water closures put the exponents of their 2^(.) in place by integer addition (water_closures_log); the
+// host decides (DevParams::vg_fast_all), clay-like ensembles run the VGF = false instantiation.
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false, bool VGF = true>
 __global__ void __launch_bounds__((rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()),
                                   (rhs_min_waves<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()))
 rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
@@ -355,6 +364,22 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         for (int j = 1; j < CPL; ++j) c[j] = c[0];
     }
 
+    constexpr bool vgf = VGF && M::uses_tables; // integer-exponent 2^(.) (a host decision)
+    // Fluxes are carried in units of the TENDENCY: the arithmetic-mean factor 1/2 of InterpolateC2F,
+    // the 1/dz of GradientC2F and the 1/dz of DivergenceF2C are one constant cg = (1/2)/dz^2 applied to
+    // the centre difference, and (production math) the closures return K WITHOUT Ksat, which joins cg in
+    // the per-column constant of the water flux: two multiplications per cell less than
+    // F = -(K_lo + K_hi) (dh (1/2)/dz), -(F_hi - F_lo)/dz, a rounding-level regrouping.  Boundary
+    // fluxes (physical units, boundary_fluxes) are scaled by 1/dz once per column.
+    constexpr bool RELK = M::is_production;
+    const FT cgT = P.half_inv_dz * P.inv_dz;
+    FT cgw[CPL], Ksc[CPL]; // water flux constant; the factor that makes a closure K a true conductivity
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        Ksc[j] = RELK ? c[j].Ksat : FT(1);
+        cgw[j] = cgT * Ksc[j];
+    }
+
     FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
     FT vl_n[PF][CPL], ti_n[PF][CPL], re_n[PF][CPL], Ta_n[PF][CPL]; // PF levels in flight
     FT kv_n[PF][CPL], ke_n[PF][CPL];               // MODE 5: k1 of those levels
@@ -368,6 +393,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // heat face diffusivities (the column constant n m and the exact factor 1/2 of the mean
     // coefficients are divided out once per column / wave at the end)
     float dpsi_p[CPL], ircs_p[CPL], DmaxW[CPL], DmaxT[CPL];
+    float DmaxWb[CPL]; // the Dirichlet-face terms, formed with TRUE conductivities (DmaxW: relative to Ksc)
 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -376,7 +402,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         yv[j] = ye[j] = yv_p[j] = ye_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
         Ta[j] = FT(288); // PrescribedTemperatureModel default (models.jl:53)
-        dpsi_p[j] = DmaxW[j] = DmaxT[j] = ircs_p[j] = 0.0f;
+        dpsi_p[j] = DmaxW[j] = DmaxWb[j] = DmaxT[j] = ircs_p[j] = 0.0f;
     }
     // loads the level the row pointers currently address into ring slot `slot`,
     // then moves the pointers one level up
@@ -408,8 +434,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         FT dvl[CPL], dre[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            dvl[j] = WATER ? -((Fw_hi[j] - Fw_lo[j]) * P.inv_dz) : FT(0);
-            dre[j] = HEAT ? -((Fe_hi[j] - Fe_lo[j]) * P.inv_dz) : FT(0);
+            dvl[j] = WATER ? Fw_lo[j] - Fw_hi[j] : FT(0); // -(F_hi - F_lo), fluxes in tendency units
+            dre[j] = HEAT ? Fe_lo[j] - Fe_hi[j] : FT(0);
             if (CPL == 1 || col0 + j < P.ncols) {
                 if (WATER) nf_acc = fma_ft(dvl[j], FT(0), nf_acc);
                 if (HEAT) nf_acc = fma_ft(dre[j], FT(0), nf_acc);
@@ -453,6 +479,9 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         }
     };
 
+#if LH_RHS_OUTER_UNROLL > 0
+#pragma unroll RHS_OUTER_UNROLL
+#endif
     for (int i0 = i_first; i0 < i_end; i0 += PF) {
 #pragma unroll
       for (int k = 0; k < PF; ++k) {
@@ -488,8 +517,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 if (WANT_DT) ircs[j] = float(mm.rcp(rcs[j])); // (the reciprocal temperature_closure formed)
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
-                                                                     psi[j], &dpsi[j]);
+                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE, RELK>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
+                                                                           psi[j], &dpsi[j], vgf);
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
@@ -502,11 +531,14 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 FT K_f = FT(0), kap_f = FT(0);
+                const FT K_c = K[j] * Ksc[j]; // the true conductivity of the boundary cell
                 boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
-                                                              T[j], K[j], psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f);
+                                                              T[j], K_c, psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f, vgf);
+                Fe_lo[j] = Fe_lo[j] * P.inv_dz;
+                Fw_lo[j] = Fw_lo[j] * P.inv_dz;
                 if (WANT_DT) { // the bottom cell's own coefficients; Dirichlet faces: half a cell away, face-state coefficients
                     DmaxW[j] = max_nonneg(DmaxW[j], 2.0f * float(K[j]) * dpsi[j]);
-                    DmaxW[j] = max_nonneg(DmaxW[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K[j] : FT(0))) * dpsi[j]);
+                    DmaxWb[j] = max_nonneg(DmaxWb[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K_c : FT(0))) * dpsi[j]);
                     if (HEAT) {
                         DmaxT[j] = max_nonneg(DmaxT[j], 2.0f * float(kap[j]) * ircs[j]);
                         DmaxT[j] = max_nonneg(DmaxT[j], 4.0f * float(fmax_ft(kap_f, kap_f > FT(0) ? kap[j] : FT(0))) * ircs[j]);
@@ -519,15 +551,14 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             for (int j = 0; j < CPL; ++j) {
                 Fw[j] = Fe[j] = FT(0);
                 FT gh = FT(0);
-                // -1/2 (a_lo + a_hi) (x_hi - x_lo)/dz with the exact factor 1/2 folded into 1/dz:
-                // bitwise the three-multiply form (scaling by 2 commutes with rounding), one
-                // multiply less per term
+                // -1/2 (a_lo + a_hi) (x_hi - x_lo)/dz /dz with the three constants (and Ksat) folded
+                // into the gradient's factor (see cgw above)
                 if (WATER) {
-                    gh = (h[j] - h_p[j]) * P.half_inv_dz;
+                    gh = (h[j] - h_p[j]) * cgw[j];
                     Fw[j] = -(K_p[j] + K[j]) * gh;
                 }
                 if (HEAT) {
-                    FT gT = (T[j] - T_p[j]) * P.half_inv_dz;
+                    FT gT = (T[j] - T_p[j]) * cgT;
                     Fe[j] = -(kap_p[j] + kap[j]) * gT;
                     if (WATER) Fe[j] = Fe[j] - (E_p[j] + E[j]) * gh;
                 }
@@ -565,11 +596,14 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             FT K_f = FT(0), kap_f = FT(0);
+            const FT K_c = K_p[j] * Ksc[j]; // the true conductivity of the boundary cell
             boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
-                                                          K_p[j], psi_p[j], Fe[j], Fw[j], &K_f, &kap_f);
+                                                          K_c, psi_p[j], Fe[j], Fw[j], &K_f, &kap_f, vgf);
+            Fe[j] = Fe[j] * P.inv_dz;
+            Fw[j] = Fw[j] * P.inv_dz;
             if (WANT_DT) { // the top cell's own coefficients, and the Dirichlet face's
                 DmaxW[j] = max_nonneg(DmaxW[j], 2.0f * float(K_p[j]) * dpsi_p[j]);
-                DmaxW[j] = max_nonneg(DmaxW[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K_p[j] : FT(0))) * dpsi_p[j]);
+                DmaxWb[j] = max_nonneg(DmaxWb[j], 4.0f * float(fmax_ft(K_f, K_f > FT(0) ? K_c : FT(0))) * dpsi_p[j]);
                 if (HEAT) {
                     DmaxT[j] = max_nonneg(DmaxT[j], 2.0f * float(kap_p[j]) * ircs_p[j]);
                     DmaxT[j] = max_nonneg(DmaxT[j], 4.0f * float(fmax_ft(kap_f, kap_f > FT(0) ? kap_p[j] : FT(0))) * ircs_p[j]);
@@ -584,7 +618,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         float dmax = 0.0f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) { // (a column whose maximum is NaN is dropped: it is flagged through P.status)
-            const float Dj = max_nonneg(DmaxW[j] * float(FT(1) / (c[j].n * c[j].m)), DmaxT[j]);
+            const float Dj = max_nonneg(max_nonneg(DmaxW[j] * float(Ksc[j]), DmaxWb[j]) * float(FT(1) / (c[j].n * c[j].m)), DmaxT[j]);
             if ((CPL == 1 || col0 + j < P.ncols) && Dj == Dj) dmax = max_nonneg(dmax, Dj);
         }
         // Wave maximum by a binary tree through LDS (x -> fl(c/x) is monotone, so the minimum of
@@ -644,7 +678,7 @@ static inline int cs_fetch_tiles(int model, bool noice, bool need_Taux) {
     return 3; // vl, ti, rhoe (HEAT reads the first two from Ya)
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE, bool NOICE = false>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE, bool NOICE = false, bool VGF = true>
 __global__ void __launch_bounds__(1024)
 column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
                       const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
@@ -687,6 +721,12 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const int64_t col = col_raw < P.ncols ? col_raw : P.ncols - 1; // spare slots shadow the last column
     ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
     if (WATER && !NOICE) finish_colc<FT, M>(mm, c);
+    constexpr bool vgf = VGF && M::uses_tables; // (as rhs_kernel)
+    // fluxes in tendency units, K without Ksat: rhs_kernel's constants and expressions, to the letter
+    constexpr bool RELK = M::is_production;
+    const FT cgT = P.half_inv_dz * P.inv_dz;
+    const FT Ksc = RELK ? c.Ksat : FT(1);
+    const FT cgw = cgT * Ksc;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     // Planes are column-fastest, threads here are level-fastest: go through LDS tiles so that
     // global memory sees the cpb adjacent columns of a level as one contiguous piece.  All
@@ -732,7 +772,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 kap = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl, ti);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, u_vl, ti, T, K, psi);
+                water_closures<FT, M, FACTORS, true, false, NOICE, RELK>(mm, P, c, u_vl, ti, T, K, psi, nullptr, vgf);
                 h = psi + z;
                 if (HEAT) E = (P.rhocp_l * (T - P.T_ref)) * K; // rho_e_int_l * K (:364)
             }
@@ -748,40 +788,45 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             // TOGETHER (one divergent pass, not two, when both faces need closures)
             FT Fw_b = FT(0), Fe_b = FT(0);
             const bool at_bottom = (i == 0), at_top = (i == n - 1);
-            if (i < n && (at_bottom || at_top))
+            if (i < n && (at_bottom || at_top)) {
                 boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, u_vl, ti,
-                                                              T, K, psi, Fe_b, Fw_b);
+                                                              T, K * Ksc, psi, Fe_b, Fw_b, nullptr, nullptr, vgf);
+                Fe_b = Fe_b * P.inv_dz;
+                Fw_b = Fw_b * P.inv_dz;
+            }
             if (i < n) {
                 if (at_bottom) {
                     Fw_lo = Fw_b;
                     Fe_lo = Fe_b;
                 } else {
                     FT gh = FT(0);
-                    if (WATER) { // (as rhs_kernel: the factor 1/2 folded into 1/dz)
-                        gh = (h - sh[i - 1]) * P.half_inv_dz;
+                    if (WATER) { // (as rhs_kernel)
+                        gh = (h - sh[i - 1]) * cgw;
                         Fw_lo = -(sK[i - 1] + K) * gh;
                     }
                     if (HEAT) {
-                        const FT gT = (T - sT[i - 1]) * P.half_inv_dz;
+                        const FT gT = (T - sT[i - 1]) * cgT;
                         Fe_lo = -(sKap[i - 1] + kap) * gT;
                         if (WATER) Fe_lo = Fe_lo - (sE[i - 1] + E) * gh;
                     }
                 }
                 if (at_top) {
-                    if (at_bottom) // a one-cell column: the same thread owns both faces
-                        boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K, psi, Fe_hi, Fw_hi);
-                    else {
+                    if (at_bottom) { // a one-cell column: the same thread owns both faces
+                        boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K * Ksc, psi, Fe_hi, Fw_hi, nullptr, nullptr, vgf);
+                        Fe_hi = Fe_hi * P.inv_dz;
+                        Fw_hi = Fw_hi * P.inv_dz;
+                    } else {
                         Fw_hi = Fw_b;
                         Fe_hi = Fe_b;
                     }
                 } else if (!WAVE) { // (one-wave columns read the neighbour's flux below instead)
                     FT gh = FT(0);
                     if (WATER) {
-                        gh = (sh[i + 1] - h) * P.half_inv_dz;
+                        gh = (sh[i + 1] - h) * cgw;
                         Fw_hi = -(K + sK[i + 1]) * gh;
                     }
                     if (HEAT) {
-                        const FT gT = (sT[i + 1] - T) * P.half_inv_dz;
+                        const FT gT = (sT[i + 1] - T) * cgT;
                         Fe_hi = -(kap + sKap[i + 1]) * gT;
                         if (WATER) Fe_hi = Fe_hi - (E + sE[i + 1]) * gh;
                     }
@@ -801,8 +846,8 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                     if (HEAT) Fe_hi = sFe[i + 1];
                 }
             }
-            const FT dvl = WATER ? -((Fw_hi - Fw_lo) * P.inv_dz) : FT(0);
-            const FT dre = HEAT ? -((Fe_hi - Fe_lo) * P.inv_dz) : FT(0);
+            const FT dvl = WATER ? Fw_lo - Fw_hi : FT(0);
+            const FT dre = HEAT ? Fe_lo - Fe_hi : FT(0);
             if (cell) {
                 if (WATER) nf_acc = fma_ft(dvl, FT(0), nf_acc);
                 if (HEAT) nf_acc = fma_ft(dre, FT(0), nf_acc);
@@ -856,6 +901,7 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
     if (WATER) finish_colc<FT, M>(mm, c);
+    const bool vgf = M::uses_tables && P.vg_fast_all != 0; // (kernel-argument constant: a scalar branch)
     for (int i = 0; i < P.nlev; ++i) {
         const int64_t o = int64_t(i) * P.stride;
         FT vl = p_vl[o], ti = p_ti[o];
@@ -865,7 +911,7 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
             T = temperature_closure<FT, M>(mm, P, c, vl, ti, IN.v[2][o + col], rcs);
             kap = kappa_closure<FT, M>(mm, P, c, vl, ti);
         }
-        if (WATER) water_closures<FT, M, FACTORS>(mm, P, c, vl, ti, T, K, psi);
+        if (WATER) water_closures<FT, M, FACTORS>(mm, P, c, vl, ti, T, K, psi, nullptr, vgf);
         OUT.v[0][o + col] = K;
         OUT.v[1][o + col] = psi;
         OUT.v[2][o + col] = kap;
@@ -1110,7 +1156,7 @@ static inline dim3 grid_for(int64_t work, int block) {
     return dim3((unsigned)((work + block - 1) / block));
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, bool NOICE>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, bool NOICE, bool VGF = true>
 static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                             const Planes<FT>& base, const Planes<FT>& out, FT dt, const FT* dt_dev,
                             int mode, int block_req, hipStream_t s) {
@@ -1131,14 +1177,14 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
         hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, false>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
     } else {
         switch (mode) {
-            case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-            case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-            case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-            case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
-            case 5: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 5, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 0: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 1: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 1, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 2: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 2, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 3: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 3, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
+            case 5: hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 5, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev); break;
             default: // 4: tendency + stable-step bound; the minimum starts at +inf
                 hipLaunchKernelGGL((init_bits_kernel<FT>), dim3(1), dim3(1), 0, s, reinterpret_cast<typename Bits<FT>::type*>(P.dt_out));
-                hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4, NOICE>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
+                hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 4, NOICE, VGF>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
                 break;
         }
     }
@@ -1178,8 +1224,18 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
     const bool seg = M::is_production && P.seg_len > 0 && P.seg_len < P.nlev;
     // the no-ice kernels exist for the production math without conductivity factors
     const bool ni = noice && M::is_production && !factors;
+    // clay-like ensembles (some column with m < LH_VG_FAST_MIN_M): the log-domain closures, one launch
+    // shape (plain access, unsegmented) -- the Float64 water kernels only
+    constexpr bool has_robust = M::uses_tables && MODEL != MODEL_HEAT;
+    const bool robust = has_robust && P.vg_fast_all == 0;
 #define LH_GO3(F, PC, NI)                                                                             \
     do {                                                                                              \
+        if constexpr (has_robust) {                                                                   \
+            if (robust) {                                                                             \
+                launch_rhs_mode<FT, MODEL, F, PC, CFGP, M, NI, false>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
+                break;                                                                                \
+            }                                                                                         \
+        }                                                                                             \
         if (seg) launch_rhs_mode<FT, MODEL, F, PC, CFGS, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
         else if (nt) launch_rhs_mode<FT, MODEL, F, PC, CFGN, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s); \
         else launch_rhs_mode<FT, MODEL, F, PC, CFGP, M, NI>(P, in, aux, base, out, dt, dt_dev, mode, block, s);   \
@@ -1235,8 +1291,17 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     const int narr = cs_exchange_arrays<MODEL>() + (wave ? cs_flux_arrays<MODEL>() : 0);
     const unsigned dyn = (unsigned)(cpb * (size_t)(narr > tiles ? narr : tiles) * (size_t)P.nlev * sizeof(FT));
     using M = MathFast<FT>;
+    constexpr bool has_robust = M::uses_tables && MODEL != MODEL_HEAT; // (as launch_rhs_model)
+    const bool robust = has_robust && P.vg_fast_all == 0;
 #define LH_CS(F, PC, NI)                                                                                          \
     do {                                                                                                          \
+        if constexpr (has_robust) {                                                                               \
+            if (robust) {                                                                                         \
+                if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true, NI, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv); \
+                else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);    \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
         if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);  \
         else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
     } while (0)

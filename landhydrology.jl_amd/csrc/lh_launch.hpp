@@ -29,6 +29,7 @@ struct Tune {
     int xcd = 1;     // XCD-contiguous workgroup map (0: workgroup b = column block b)
     int place_mem = 0;  // lh_tune_placement: transient memory bound, percent of free memory (0 = 25)
     int zero = 1;    // use the states' known-zero plane bits (0: always read theta_i and store d theta_i = 0)
+    int vgfast = 1;  // Float64: integer-exponent 2^(.) in the water closures when every column allows it (0: v_ldexp form always)
 };
 
 // mode 0: tendency into `out`; 4: tendency + step bound; 1..3, 5: fused SSPRK33 stages (see rhs_kernel)
