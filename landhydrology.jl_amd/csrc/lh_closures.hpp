@@ -223,51 +223,51 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     if constexpr (M::uses_tables) ins = vgfast;
 
     // exponents are formed in the exp2 unit of the policy (c.e_* carry the scale)
-    FT L = FT(0);   // log2 S of an unsaturated cell (0 otherwise: K_r = 1, and sqrt(S) = 2^0 below)
-    FT Kb;          // K without the conductivity factors (FACTORS: without sqrt(S) too)
-    if (unsat) {
-        L = mm.log2(S);
-        const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
-        auto ex2 = [&](FT u) -> FT {
-            if constexpr (M::uses_tables) {
-                if (ins) return mm.exp2_scaled_ins(u);
-            }
-            return mm.exp2_scaled(u);
-        };
-        const FT w = FT(1) - ex2(a);
-        const FT Lw = mm.log2(w);
-        const FT inner = FT(1) - ex2(c.e_m * Lw);
-        Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner);
-        if (!RELK) Kb = Kb * c.Ksat;
-        if (WANT_PSI && shared) {
-            psi = -ex2(fma_ft(Lw, c.e_one, -a) * c.e_inv_n - c.e_log2_alpha);
-            if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+    auto ex2 = [&](FT u) -> FT {
+        if constexpr (M::uses_tables) {
+            if (ins) return mm.exp2_scaled_ins(u);
         }
-    } else {
-        // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
-        // compiler evaluates it for every cell and selects, six VALU instructions per cell)
-        Kb = RELK ? FT(1) : c.Ksat; // K_r = 1
+        return mm.exp2_scaled(u);
+    };
+    auto ex2_prod = [&](FT x, FT y) -> FT { // 2^(x y): the product goes into the reduction unrounded
+        if constexpr (M::uses_tables) {
+            if (ins) return mm.exp2_prod_ins(x, y);
+        }
+        return mm.exp2_scaled(x * y);
+    };
+    // EVERY lane runs the unsaturated chain (saturated cells are rare: their lanes compute values
+    // nobody uses -- table offsets are masked, nothing traps) and a wave with a saturated cell
+    // repairs those lanes in a real branch below: no divergent-branch bookkeeping per cell.
+    FT L = mm.log2(S);                             // log2 S
+    const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
+    const FT w = FT(1) - ex2(a);
+    const FT Lw = mm.log2(w);
+    const FT inner = FT(1) - ex2_prod(Lw, c.e_m);
+    FT Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner); // K without the conductivity factors (FACTORS: without sqrt(S) too)
+    if (!RELK) Kb = Kb * c.Ksat;
+    if (WANT_PSI && shared) {
+        psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
+        if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+    }
+    if (__builtin_amdgcn_ballot_w64(!unsat) != 0ull) { // (a NaN saturation lands here too, as in the reference's `S < 1 ? ... : ...`)
+        FT vin = vl; // (opaque: the compiler must not turn this block into per-cell selects)
+        asm volatile("" : "+v"(vin));
+        L = unsat ? L : FT(0);   // K_r = 1, and sqrt(S) = 2^0 in the factor product below
+        Kb = unsat ? Kb : (RELK ? FT(1) : c.Ksat);
         if (WANT_PSI && shared) {
-            FT vin = vl; // (opaque INPUT: nothing of the saturated evaluation can move above the branch)
-            asm volatile("" : "+v"(vin));
-            psi = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
-            if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
+            const FT ps = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
+            psi = unsat ? psi : ps;
+            if (WANT_DPSI) *dpsi = unsat ? *dpsi : float(c.n * c.m * c.inv_S_s);
         }
     }
     if (!NOICE && WANT_PSI && !shared) { // ice somewhere in the wave: psi from every lane's own saturation
         if (unsat_e) {
             // (unsat_e without unsat needs theta_i < 0: out of contract, L is 0 there)
-            auto ex2 = [&](FT u) -> FT {
-                if constexpr (M::uses_tables) {
-                    if (ins) return mm.exp2_scaled_ins(u);
-                }
-                return mm.exp2_scaled(u);
-            };
             const FT Le = L + (c.l2_por - mm.log2(por_e)); // log2 Se; == L bitwise for a lane without ice
             const FT ae = Le * c.e_inv_m;
             const FT we = FT(1) - ex2(ae);
             const FT Lwe = mm.log2(we);
-            psi = -ex2(fma_ft(Lwe, c.e_one, -ae) * c.e_inv_n - c.e_log2_alpha);
+            psi = -ex2(fma_ft(fma_ft(Lwe, c.e_one, -ae), c.e_inv_n, -c.e_log2_alpha));
             if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
         } else {
             const bool one = (same & (S == FT(1))) | (!same & (num == por_e));

@@ -165,6 +165,19 @@ template <> struct MathFast<double> {
         p = __builtin_fma(p, r, 0.0003384507717577858);
         return __builtin_fma(T, r * p, T);
     }
+    // 2^(x y / 2048) under exp2_scaled_ins's contract: the product enters the rounding shifter and
+    // the reduced argument through FMAs, i.e. unrounded and without an instruction of its own
+    __device__ __forceinline__ double exp2_prod_ins(double x, double y) const {
+        const double sh = __builtin_fma(x, y, shiftv);
+        const int k = __double2loint(sh);
+        const double r = __builtin_fma(x, y, -(sh - shiftv));
+        const unsigned off = ((unsigned)k << 3) & ((EXP_TAB_N - 1) << 3);
+        const double tb_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb.exp_tab) + off);
+        const double T = __hiloint2double(__double2hiint(tb_) + (int)((unsigned)k << 9), __double2loint(tb_));
+        double p = __builtin_fma(r, 6.461528679825916e-12, q2v);
+        p = __builtin_fma(p, r, 0.0003384507717577858);
+        return __builtin_fma(T, r * p, T);
+    }
     __device__ __forceinline__ double exp2_core(double t) const { return exp2_scaled(t * EXP2_SCALE); }
 
     // x^y with libm's results for the special bases the closures can produce:
