@@ -201,6 +201,16 @@ __device__ __forceinline__ float max_nonneg(float a, float b) {
     return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
 }
 
+// Orders one wave's LDS traffic around a hand-off between its lanes: the LDS operations of a wave
+// execute in order, so no instruction is needed -- the wave barrier pins the compiler's schedule and
+// the two wavefront-scope fences (no code on gfx950) keep it from moving a load of another lane's
+// word above the store that produced it.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename FT>
 __device__ __forceinline__ bool finite(FT x) {
     return x - x == FT(0);
@@ -634,7 +644,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         seg[l] = dmax;
 #pragma unroll
         for (unsigned off = 32; off > 0; off >>= 1) {
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
             if (l < off) {
                 dmax = max_nonneg(dmax, seg[l + off]);
                 seg[l] = dmax;
@@ -781,7 +791,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 if (HEAT) { sT[i] = T; sKap[i] = kap; }
                 if (HEAT && WATER) sE[i] = E;
             }
-            if (WAVE) __builtin_amdgcn_wave_barrier();
+            if (WAVE) wave_sync();
             else __syncthreads();
             FT Fw_lo = FT(0), Fe_lo = FT(0), Fw_hi = FT(0), Fe_hi = FT(0);
             // boundary faces: the bottom thread and the top thread go through boundary_fluxes
@@ -840,7 +850,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                     if (WATER) sFw[i] = Fw_lo;
                     if (HEAT) sFe[i] = Fe_lo;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
                 if (i < n - 1) {
                     if (WATER) Fw_hi = sFw[i + 1];
                     if (HEAT) Fe_hi = sFe[i + 1];
@@ -862,7 +872,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             };
             if (WATER) u_vl = upd(y_vl, u_vl, dvl);
             if (HEAT) u_re = upd(y_re, u_re, dre);
-            if (WAVE) __builtin_amdgcn_wave_barrier(); // neighbours have read this stage's LDS values
+            if (WAVE) wave_sync(); // neighbours have read this stage's LDS values
             else __syncthreads();
         }
         y_vl = u_vl;
@@ -883,6 +893,249 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
         }
     }
     if (cell && nf_acc != nf_acc) atomicOr(P.status, 1u);
+}
+
+// ----------------------------------- persistent column stepper, one wave per column
+//
+// column_stepper_kernel's one-wave form for columns of up to 64 CW levels: lane l of the column's
+// wave owns the CW ADJACENT cells CW l .. CW l + CW - 1, so the faces between them are evaluated in
+// the lane, and only the lane's top cell travels through LDS (to lane l + 1) and the flux of the face
+// below its bottom cell back (to lane l - 1): every interior face is evaluated ONCE, with
+// rhs_kernel's expression (lower cell first), no workgroup barrier anywhere in the time loop (LDS
+// operations of one wave execute in order) -- bitwise the fused stages.  CW = 1: columns of <= 64
+// levels; CW = 2: the 128-level configurations, which the thread-per-cell form runs with two waves
+// per column, two workgroup barriers per stage and every interior face evaluated twice.
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int CW, bool NOICE = false, bool VGF = true>
+__global__ void __launch_bounds__(1024)
+column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
+                           const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const int n = P0.nlev; // <= 64 CW (the launcher's choice of CW)
+    const int slot = int(threadIdx.x) >> 6; // column of this workgroup
+    const int l = int(threadIdx.x) & 63;    // lane = CW adjacent cells
+    const int cpb = int(blockDim.x) >> 6;
+    const FT dt = dt_device ? *dt_device : dt_value;
+    // per column: the top cell of every lane -- (K, h), (T, kappa), rho_e_l K as the model needs --
+    // and the flux(es) of the face below every lane's bottom cell; 64 words each
+    constexpr int NEX = cs_exchange_arrays<MODEL>();
+    constexpr int NARR = NEX + cs_flux_arrays<MODEL>();
+    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * 64;
+    FT* sh = sK + 64;
+    FT* sT = WATER ? sh + 64 : sK;
+    FT* sKap = sT + 64;
+    FT* sE = sKap + 64;
+    FT* sFw = reinterpret_cast<FT*>(s_dyn) + (size_t(slot) * NARR + NEX) * 64;
+    FT* sFe = WATER ? sFw + 64 : sFw;
+    const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
+    if (!M::uses_tables) __syncthreads();
+    DevParams<FT> P = P0; // boundary values change per stage
+    unsigned blk = blockIdx.x; // XCD-contiguous workgroup map (as rhs_kernel)
+    if (P.xcd_remap) {
+        const unsigned per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const int64_t col_raw = int64_t(blk) * cpb + slot;
+    const int64_t col = col_raw < P.ncols ? col_raw : P.ncols - 1; // spare slots shadow the last column
+    ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    if (WATER && !NOICE) finish_colc<FT, M>(mm, c);
+    constexpr bool vgf = VGF && M::uses_tables;
+    constexpr bool RELK = M::is_production; // fluxes in tendency units, K without Ksat: as rhs_kernel, to the letter
+    const FT cgT = P.half_inv_dz * P.inv_dz;
+    const FT Ksc = RELK ? c.Ksat : FT(1);
+    const FT cgw = cgT * Ksc;
+    const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
+    // planes are column-fastest, lanes here level-fastest: through LDS tiles [cpb][n] (column_stepper_kernel)
+    FT* tiles = reinterpret_cast<FT*>(s_dyn);
+    const int64_t col_first = int64_t(blk) * cpb;
+    const int tile_n = n * cpb;
+    auto request = [&](const FT* plane, int k) {
+        for (int e = threadIdx.x; e < tile_n; e += blockDim.x) {
+            const int lev = e / cpb, cs = e - lev * cpb;
+            if (col_first + cs < P.ncols) tiles[k * tile_n + cs * n + lev] = plane[int64_t(lev) * P.stride + col_first + cs];
+        }
+    };
+    request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
+    if (!NOICE) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
+    if (HEAT) request(Y.v[2], 2);
+    if (need_Taux) request(AUX.v[3], 3);
+    __syncthreads();
+    FT y_vl[CW], y_re[CW], ti[CW], Ta[CW], z[CW];
+    bool act[CW]; // the cell exists (and the column does)
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+        const int i = CW * l + q;
+        const int ic = i < n ? i : n - 1;
+        act[q] = i < n && col_raw < P.ncols;
+        const bool have = col_raw < P.ncols;
+        y_vl[q] = have ? tiles[slot * n + ic] : FT(0);
+        ti[q] = (!NOICE && have) ? tiles[tile_n + slot * n + ic] : FT(0); // NOICE: the theta_i plane is known to be all zeros
+        y_re[q] = (HEAT && have) ? tiles[2 * tile_n + slot * n + ic] : FT(0);
+        Ta[q] = (need_Taux && have) ? tiles[3 * tile_n + slot * n + ic] : FT(288);
+        z[q] = P.zc[ic];
+    }
+    __syncthreads(); // the tiles overlay other columns' exchange arrays
+    const int lt = (n - 1) / CW, qt = (n - 1) - lt * CW; // lane and slot of the top cell
+    FT nf_acc = FT(0);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        FT u_vl[CW], u_re[CW]; // the stage state
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+            u_vl[q] = y_vl[q];
+            u_re[q] = y_re[q];
+        }
+#pragma unroll 1
+        for (int stage = 0; stage < 3; ++stage) {
+            if (bcv) {
+                const FT* b = bcv + (s * 3 + stage) * 4;
+                P.bc_value[0][0] = b[0];
+                P.bc_value[0][1] = b[1];
+                P.bc_value[1][0] = b[2];
+                P.bc_value[1][1] = b[3];
+            }
+            FT T[CW], kap[CW], K[CW], psi[CW], h[CW], E[CW];
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                FT rcs = FT(1);
+                T[q] = Ta[q];
+                kap[q] = K[q] = psi[q] = h[q] = E[q] = FT(0);
+                if (HEAT) {
+                    T[q] = temperature_closure<FT, M, NOICE>(mm, P, c, u_vl[q], ti[q], u_re[q], rcs);
+                    kap[q] = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl[q], ti[q]);
+                }
+                if (WATER) {
+                    water_closures<FT, M, FACTORS, true, false, NOICE, RELK>(mm, P, c, u_vl[q], ti[q], T[q], K[q], psi[q], nullptr, vgf);
+                    h[q] = psi[q] + z[q];
+                    if (HEAT) E[q] = (P.rhocp_l * (T[q] - P.T_ref)) * K[q]; // rho_e_int_l * K (:364)
+                }
+            }
+            // the lane's top cell, for the lane above
+            if (WATER) { sK[l] = K[CW - 1]; sh[l] = h[CW - 1]; }
+            if (HEAT) { sT[l] = T[CW - 1]; sKap[l] = kap[CW - 1]; }
+            if (HEAT && WATER) sE[l] = E[CW - 1];
+            wave_sync();
+            // boundary faces: the lane with the bottom cell and the lane with the top cell go through
+            // boundary_fluxes TOGETHER (one divergent pass, not two, when both faces need closures)
+            FT Fw_b = FT(0), Fe_b = FT(0), Fw_t = FT(0), Fe_t = FT(0);
+            const bool at_bottom = (l == 0), at_top = (l == lt);
+            if (at_bottom || at_top) {
+                // (the top cell's slot qt is uniform: a chain of selects over the unrolled slots)
+                FT bv = u_vl[0], bti = ti[0], bT = T[0], bK = K[0], bpsi = psi[0];
+                if (!at_bottom) {
+#pragma unroll
+                    for (int q = 1; q < CW; ++q)
+                        if (q == qt) { bv = u_vl[q]; bti = ti[q]; bT = T[q]; bK = K[q]; bpsi = psi[q]; }
+                }
+                FT fe, fw;
+                boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, bv, bti, bT,
+                                                              bK * Ksc, bpsi, fe, fw, nullptr, nullptr, vgf);
+                fe = fe * P.inv_dz;
+                fw = fw * P.inv_dz;
+                if (at_bottom) { Fe_b = fe; Fw_b = fw; }
+                else { Fe_t = fe; Fw_t = fw; }
+                if (at_bottom && at_top) { // a column of <= CW cells: the same lane owns both faces
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+                        if (q == qt) { bv = u_vl[q]; bti = ti[q]; bT = T[q]; bK = K[q]; bpsi = psi[q]; }
+                    boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, bv, bti, bT, bK * Ksc, bpsi, Fe_t, Fw_t,
+                                                                  nullptr, nullptr, vgf);
+                    Fe_t = Fe_t * P.inv_dz;
+                    Fw_t = Fw_t * P.inv_dz;
+                }
+            }
+            // F[q]: the face below the lane's cell q; F[CW]: the face above its top cell
+            FT Fw[CW + 1], Fe[CW + 1];
+#pragma unroll
+            for (int q = 0; q <= CW; ++q) Fw[q] = Fe[q] = FT(0);
+            if (at_bottom) {
+                Fw[0] = Fw_b;
+                Fe[0] = Fe_b;
+            } else { // (as rhs_kernel: lower cell first)
+                FT gh = FT(0);
+                if (WATER) {
+                    gh = (h[0] - sh[l - 1]) * cgw;
+                    Fw[0] = -(sK[l - 1] + K[0]) * gh;
+                }
+                if (HEAT) {
+                    const FT gT = (T[0] - sT[l - 1]) * cgT;
+                    Fe[0] = -(sKap[l - 1] + kap[0]) * gT;
+                    if (WATER) Fe[0] = Fe[0] - (sE[l - 1] + E[0]) * gh;
+                }
+            }
+#pragma unroll
+            for (int q = 1; q < CW; ++q) {
+                FT gh = FT(0);
+                if (WATER) {
+                    gh = (h[q] - h[q - 1]) * cgw;
+                    Fw[q] = -(K[q - 1] + K[q]) * gh;
+                }
+                if (HEAT) {
+                    const FT gT = (T[q] - T[q - 1]) * cgT;
+                    Fe[q] = -(kap[q - 1] + kap[q]) * gT;
+                    if (WATER) Fe[q] = Fe[q] - (E[q - 1] + E[q]) * gh;
+                }
+            }
+            // the face above the lane's top cell is the face below the next lane's bottom cell
+            if (WATER) sFw[l] = Fw[0];
+            if (HEAT) sFe[l] = Fe[0];
+            wave_sync();
+            if (l < 63) {
+                if (WATER) Fw[CW] = sFw[l + 1];
+                if (HEAT) Fe[CW] = sFe[l + 1];
+            }
+            if (at_top) { // the face above the column's top cell (slot qt) is the boundary
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
+                    if (q == qt) { Fw[q + 1] = Fw_t; Fe[q + 1] = Fe_t; }
+            }
+            // the stage updates of rhs_kernel MODE 1..3 (b = Y, u = stage state)
+            auto upd = [&](FT b, FT u, FT k) -> FT {
+                if (stage == 0) return u + dt * k;
+                if (stage == 1) return (FT(3) * b + u + dt * k) * FT(0.25);
+                const FT sum = b + FT(2) * u + FT(2) * dt * k;
+                const FT qq = sum * FT(1.0 / 3.0);
+                return fma_ft(fma_ft(FT(-3), qq, sum), FT(1.0 / 3.0), qq);
+            };
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const FT dvl = WATER ? Fw[q] - Fw[q + 1] : FT(0);
+                const FT dre = HEAT ? Fe[q] - Fe[q + 1] : FT(0);
+                if (act[q]) {
+                    if (WATER) nf_acc = fma_ft(dvl, FT(0), nf_acc);
+                    if (HEAT) nf_acc = fma_ft(dre, FT(0), nf_acc);
+                }
+                if (WATER) u_vl[q] = upd(y_vl[q], u_vl[q], dvl);
+                if (HEAT) u_re[q] = upd(y_re[q], u_re[q], dre);
+            }
+            wave_sync(); // the neighbours have read this stage's LDS values
+        }
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+            y_vl[q] = u_vl[q];
+            y_re[q] = u_re[q];
+        }
+    }
+    __syncthreads(); // the tiles overlay other columns' exchange arrays
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+        const int i = CW * l + q;
+        if (i < n) {
+            if (WATER) tiles[slot * n + i] = y_vl[q];
+            if (HEAT) tiles[tile_n + slot * n + i] = y_re[q];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tile_n; e += blockDim.x) {
+        const int lev = e / cpb, cs = e - lev * cpb;
+        if (col_first + cs < P.ncols) {
+            const int64_t g = int64_t(lev) * P.stride + col_first + cs;
+            if (WATER) Y.v[0][g] = tiles[cs * n + lev];
+            if (HEAT) Y.v[2][g] = tiles[tile_n + cs * n + lev];
+        }
+    }
+    if (col_raw < P.ncols && nf_acc != nf_acc) atomicOr(P.status, 1u);
 }
 
 // --------------------------------------------------------- diagnostics
@@ -1272,38 +1525,46 @@ template <typename FT, int MODEL>
 void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux,
                                      FT dt, const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors,
                                      bool percol, bool noice, hipStream_t s) {
-    const unsigned tpc = (unsigned)((P.nlev + 63) / 64 * 64);
-    // columns per workgroup
-    // columns per workgroup: 256 threads when the stages need workgroup barriers; 8 one-wave
-    // columns otherwise (64-byte pieces of every plane row: tile I/O 0.43 instead of 0.79 ms
-    // on 1e6 x 64 Float64, tools/microbench/tile_io_probe.hip)
-    const bool wave = tpc == 64;
+    // One wave per column with 1 or 2 adjacent cells per lane (column_stepper_wave_kernel) for columns
+    // of up to 128 levels; one thread per cell with workgroup barriers beyond that.
+    const int cw = (P.nlev + 63) / 64;
+    const bool wave = cw <= 2;
+    const unsigned tpc = wave ? 64u : (unsigned)((P.nlev + 63) / 64 * 64);
+    // columns per workgroup: 8 one-wave columns (64-byte pieces of every plane row: tile I/O 0.43
+    // instead of 0.79 ms on 1e6 x 64 Float64, tools/microbench/tile_io_probe.hip); 256 threads when
+    // the stages need workgroup barriers.
     // The Float64 math tables take 48 KiB of LDS per workgroup whatever its size, so large
     // ensembles of Float64 columns run 512-thread workgroups (2 per CU; measured on 1e6 columns:
-    // 64 levels 0.75 / 0.68 / 0.78 ms per step with 256 / 512 / 1024 threads, 128 levels
-    // 1.65 / 1.51 / 1.80); Float32 (no tables) keeps 8 one-wave columns / 256 threads.
+    // 64 levels 0.75 / 0.68 / 0.78 ms per step with 256 / 512 / 1024 threads)
     unsigned cpb = wave ? 8u : (256u / tpc ? 256u / tpc : 1u);
     if (sizeof(FT) == 8 && P.ncols >= 4096) cpb = 512u / tpc ? 512u / tpc : 1u;
     if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;
     dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && factors && P.viscosity_kind;
     const int tiles = cs_fetch_tiles(MODEL, noice && !factors, need_Taux);
+    // dynamic LDS: the plane tiles of the initial fetch and the exchange arrays share it
     const int narr = cs_exchange_arrays<MODEL>() + (wave ? cs_flux_arrays<MODEL>() : 0);
-    const unsigned dyn = (unsigned)(cpb * (size_t)(narr > tiles ? narr : tiles) * (size_t)P.nlev * sizeof(FT));
+    const size_t ex_words = wave ? (size_t)narr * 64 : (size_t)narr * (size_t)P.nlev;
+    const size_t tile_words = (size_t)tiles * (size_t)P.nlev;
+    const unsigned dyn = (unsigned)(cpb * (ex_words > tile_words ? ex_words : tile_words) * sizeof(FT));
     using M = MathFast<FT>;
     constexpr bool has_robust = M::uses_tables && MODEL != MODEL_HEAT; // (as launch_rhs_model)
     const bool robust = has_robust && P.vg_fast_all == 0;
-#define LH_CS(F, PC, NI)                                                                                          \
-    do {                                                                                                          \
-        if constexpr (has_robust) {                                                                               \
-            if (robust) {                                                                                         \
-                if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true, NI, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv); \
-                else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI, false>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);    \
-                break;                                                                                            \
-            }                                                                                                     \
-        }                                                                                                         \
-        if (wave) hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, true, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);  \
-        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
+#define LH_CS_GO(F, PC, NI, VG)                                                                                                        \
+    do {                                                                                                                               \
+        if (wave && cw == 1) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv); \
+        else if (wave) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
+        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);                \
+    } while (0)
+#define LH_CS(F, PC, NI)                                    \
+    do {                                                    \
+        if constexpr (has_robust) {                         \
+            if (robust) {                                   \
+                LH_CS_GO(F, PC, NI, false);                 \
+                break;                                      \
+            }                                               \
+        }                                                   \
+        LH_CS_GO(F, PC, NI, true);                          \
     } while (0)
     if (factors) {
         if (percol) LH_CS(true, true, false);
@@ -1315,6 +1576,7 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
         if (percol) LH_CS(false, true, false);
         else LH_CS(false, false, false);
     }
+#undef LH_CS_GO
 #undef LH_CS
 }
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import sys
 from dataclasses import dataclass, field
 from typing import Optional
@@ -134,9 +135,18 @@ def wetting_front(ncols, n, zmin, zmax, nu, col_offset=0):
     return nu * (0.35 + 0.5 * sigmoid((zc[None, :] - zf[:, None]) / 0.1))
 
 
-def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Case:
+def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0, _nlev: Optional[int] = None) -> Case:
     """The BASELINE configs at test sizes plus edge cases."""
     f64, f32 = np.float64, np.float32
+    # "<family>_nNNN": the family's case with NNN levels (tall and ragged columns: 65..128 levels are
+    # one wavefront with two cells per lane in the persistent stepper, more than 128 one thread per cell)
+    nlev_override = None
+    mm_ = re.match(r"^(.*)_n(\d+)$", name)
+    if mm_:
+        name, nlev_override = mm_.group(1), int(mm_.group(2))
+        case = make_case(name, ncols, col_offset, _nlev=nlev_override)
+        case.name = f"{name}_n{nlev_override}"
+        return case
     if name == "c1_dirichlet_f64":
         # C1: 1 column, n=64, zlim=(-1.28,0), loam, Dirichlet 0.35 top / 0.20 bottom
         n, N = 64, ncols or 1
@@ -147,7 +157,9 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
     if name in ("c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128"):
         n = 128 if name.startswith("c4") else 64
         zmin = -2.56 if n == 128 else -1.28
-        N = ncols or 1000
+        if _nlev:
+            n, zmin = _nlev, -0.02 * _nlev
+        N = ncols or (1000 if not _nlev else 300)
         dt = f32 if name.endswith("f32") else f64
         om = M.CaseModel(M.MODEL_RICHARDS, n, zmin, 0.0, bc=_flux_bcs(hydrology=0.0))
         vl = wetting_front(N, n, zmin, 0.0, om.soil.nu, col_offset).astype(dt)
@@ -232,7 +244,7 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0) -> Ca
     if name in ("mixed_smooth_f64", "mixed_smooth_f32"):
         # steppable variant of the above: smooth fields with ice lenses, saturated
         # zones, both conductivity factors, Dirichlet top / free drainage bottom
-        n, N = 48, ncols or 200
+        n, N = _nlev or 48, ncols or 200
         dt = f32 if name.endswith("f32") else f64
         sp, vg = coupled_soil()
         bc = {(M.FACE_TOP, M.COMP_HYDROLOGY): (M.BC_DIRICHLET, 0.42),

@@ -98,7 +98,15 @@ def test_graph_replayed_steps_equal_plain_launches(name):
         np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
 
 
-@pytest.mark.parametrize("name", CASES + ["single_cell_f64"])
+# tall and ragged columns: 65..128 levels step as ONE wavefront with two adjacent cells per lane
+# (column_stepper_wave_kernel, CW = 2: odd counts leave the top lane half empty, 97 and 66 leave
+# whole lanes empty), more than 128 levels as one thread per cell with workgroup barriers
+TALL = ["c4_richards_f64_128", "c2_richards_f64_n97", "c2_richards_f64_n66", "c2_richards_f32_n127",
+        "mixed_smooth_f64_n101", "mixed_smooth_f32_n128", "c2_richards_f64_n150", "mixed_smooth_f32_n131",
+        "c2_richards_f64_n3", "mixed_smooth_f64_n2"]
+
+
+@pytest.mark.parametrize("name", CASES + ["single_cell_f64"] + TALL)
 def test_persistent_column_stepper_is_bitwise_the_fused_stages(name):
     """Ensembles of few columns step inside ONE launch (workgroup = column, thread = cell,
     column_stepper_kernel).  Same closures, same face expressions, same stage updates as

@@ -19,7 +19,7 @@ import parity_cases as pc
 workload = sys.argv[1]
 names = sys.argv[2:]
 ncols = int(os.environ.get("NCOLS", "1000000"))
-mode = os.environ.get("MODE", "rhs")     # rhs | rhs_dt | step
+mode = os.environ.get("MODE", "rhs")     # rhs | rhs_dt | step | persist
 case = bench.build_case(workload, ncols, 0)
 bpc = bench.WORKLOADS[workload][1]
 F = pc._pkg()._ffi
@@ -57,19 +57,21 @@ for rnd in range(4):
                 g.rhs(Y, Ya, dY)
             elif mode == "rhs_dt":
                 F.check(L.lh_rhs_stable_dt(ctx, 0.0, Y, Ya, dY, 0.4, C.c_void_p(dbuf.data_ptr())), ctx)
+            elif mode == "persist":   # 30 steps in one call: the engine lh_step_ssprk33 chooses (persistent column stepper)
+                F.check(L.lh_step_ssprk33(ctx, Y, Ya, 0.0, 1e-9, 30, None), ctx)
             else:   # 3 fused stage kernels per step; tiny dt keeps the state where it is
                 F.check(L.lh_step_ssprk33(ctx, Y, Ya, 0.0, 1e-9, 1, None), ctx)
-        for _ in range(5):
+        for _ in range(5 if mode != "persist" else 1):
             once()
-        if rnd == 0 and mode != "step":
+        if rnd == 0 and mode in ("rhs", "rhs_dt"):
             outs[nm] = g.download(dY, var)
         F.check(L.lh_timer_start(ctx), ctx)
-        reps = 40 if mode != "step" else 14
+        reps = {"step": 14, "persist": 3}.get(mode, 40)
         for _ in range(reps):
             once()
         ms = C.c_float()
         F.check(L.lh_timer_stop(ctx, C.byref(ms)), ctx)
-        res[nm].append(ms.value / reps / (3 if mode == "step" else 1))
+        res[nm].append(ms.value / reps / {"step": 3, "persist": 30}.get(mode, 1))   # step: per evaluation; persist: per step
 print(f"workload {workload} mode {mode}: {ncols} cols x {case.om.nlev} lev, {bpc} B/cell")
 ref = outs.get(names[0])
 def plane_ptrs(g, st, nvars):
