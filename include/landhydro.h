@@ -218,12 +218,29 @@ int lh_download(lh_ctx*, const lh_state*, int32_t var, void* host, int64_t lev_s
  * what interior_values(X, face, cs) hands to a host-evaluated boundary condition
  * (boundary_conditions.jl:174-186, 516-533) -- ncols values instead of a plane */
 int lh_download_level(lh_ctx*, const lh_state*, int32_t var, int32_t level, void* host);
+/* A LEVEL-UNIFORM variable: host = FT[nlev], one value per level (bottom first), the same in every
+ * column -- what Ya.soil.T .= T_profile.(zc, t) / theta_l_profile / theta_i_profile produce
+ * (make_update_aux, right_hand_side.jl:54-81: functions of z and t only) and what an initial
+ * condition f(z) gives.  nlev numbers cross PCIe instead of a plane, asynchronously (pinned staging;
+ * the call does not wait).  The column kernels take a level-uniform prescribed field of Ya (T of the
+ * Richards viscosity factor, vartheta_l and theta_i of the heat-only model) from LDS beside z and
+ * read no plane for it (8 B per cell less on the viscosity configuration); every other use
+ * (download, a prognostic variable, diagnostics, device pointers) first broadcasts the profile into
+ * the plane on the device.  Results are bitwise those of uploading the broadcast plane. */
+int lh_upload_profile(lh_ctx*, lh_state*, int32_t var, const void* host_nlev);
 int lh_state_fill(lh_ctx*, lh_state*, int32_t var, double value);
 int lh_state_copy(lh_ctx*, lh_state* dst, const lh_state* src);
 /* zero-copy access: device pointer of a plane and its element strides
  * (column-fastest planes: col_stride == 1). */
 int lh_state_device_ptr(lh_ctx*, const lh_state*, int32_t var, void** dptr,
                         int64_t* lev_stride, int64_t* col_stride);
+/* While a plane's pointer is out, the caller may write through it at any time, so the library assumes
+ * nothing about that plane: its contents are re-read at every launch (never treated as a plane of known
+ * zeros, whatever lh_state_fill / lh_state_copy / lh_rhs wrote into it since), and the identically zero
+ * d theta_i of a tendency state is re-stored at every lh_rhs.  lh_state_release_ptr ends that: the
+ * caller promises not to write through pointers obtained before the call (var = -1: every plane of
+ * the state).  Pointers stay valid addresses until the state is destroyed or moved (lh_tune_placement). */
+int lh_state_release_ptr(lh_ctx*, lh_state*, int32_t var);
 /* coordinates(cs) (right_hand_side.jl:7-8): cell-centre z, nlev doubles */
 int lh_coordinates(const lh_ctx*, double* zc_host);
 
@@ -311,7 +328,9 @@ int lh_step_ssprk33_device_dt(lh_ctx*, lh_state* Y, const lh_state* Ya, double t
  * Boundary values are the constants of lh_set_bc (a time-dependent Dirichlet closure needs the
  * stage times on the host: use the per-step calls).  dt_device_ft: one FT in device memory,
  * holds the last step's dt afterwards; elapsed_device_ft: NULL or one FT in device memory that
- * accumulates the simulated time.  Does not synchronise. */
+ * accumulates the simulated time (the caller zeroes it, on a stream ordered before this call: the
+ * context's own stream is non-blocking).  A step whose bound is not a positive finite number is
+ * taken with dt = 0 and sets bit 2 of lh_get_status.  Does not synchronise. */
 int lh_step_ssprk33_adaptive(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double courant,
                              double dt_max, int64_t nsteps, void* dt_device_ft, void* elapsed_device_ft);
 
@@ -360,7 +379,9 @@ int lh_allreduce_min(lh_ctx*, void* value_device_ft);
 
 /* bit 0: a non-finite tendency was produced since the last call (the reference
  * would have raised DomainError from `^`); bit 1: the Monin-Obukhov system of the
- * prescribed-atmosphere BC had no root in some column; synchronises and clears. */
+ * prescribed-atmosphere BC had no root in some column; bit 2: a step of
+ * lh_step_ssprk33_adaptive found no positive finite step bound (no positive diffusivity anywhere and
+ * no dt_max, or a NaN) and was taken with dt = 0; synchronises and clears. */
 int lh_get_status(lh_ctx*, uint32_t* flags);
 int lh_synchronize(lh_ctx*);
 /* Streaming ceiling of the column launch on a given set of planes (measurement aid, no

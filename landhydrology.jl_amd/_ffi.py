@@ -84,10 +84,12 @@ SIGNATURES = {
     "lh_upload": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lh_download": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lh_download_level": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "lh_upload_profile": (C.c_int, [_P, _P, C.c_int32, _P]),
     "lh_state_fill": (C.c_int, [_P, _P, C.c_int32, C.c_double]),
     "lh_state_copy": (C.c_int, [_P, _P, _P]),
     "lh_state_device_ptr": (C.c_int, [_P, _P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64)]),
+    "lh_state_release_ptr": (C.c_int, [_P, _P, C.c_int32]),
     "lh_coordinates": (C.c_int, [_P, _DP]),
     "lh_rhs": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "lh_rhs_stable_dt": (C.c_int, [_P, C.c_double, _P, _P, _P, C.c_double, _P]),

@@ -53,6 +53,16 @@ struct lh_state {
     // neither reads a theta_i plane known to be zero (rhs_kernel NOICE) nor re-stores the
     // identically zero d theta_i into a plane that already holds zeros (no kernel stores it).
     uint32_t zero_mask;
+    // Planes whose device pointer was handed out (lh_state_device_ptr) and not released
+    // (lh_state_release_ptr): the caller may write through the pointer at any time, so the library
+    // assumes NOTHING about their contents -- the zero bit is never set for them (a zero fill, a copy
+    // of a zero plane or the d theta_i = 0 clear of lh_rhs still write the zeros, every time).
+    uint32_t exposed_mask;
+    // LEVEL-UNIFORM variables (lh_upload_profile): profile[var] holds FT[nlev] on the device and IS the
+    // variable; stale_mask marks planes that have not received those values (the column kernels read a
+    // prescribed profile of Ya from LDS and never need them; everything else materialises first)
+    uint32_t profile_mask, stale_mask;
+    void* profile[LH_NVARS];
     void* plane[LH_NVARS]; // what kernels address (a slot of a context arena)
 };
 
@@ -84,6 +94,8 @@ struct lh_ctx {
     void* d_atm_pc[3] = {};            // per-column u_atm / theta_atm / q_atm (FT[ncols]) or null
     void* d_atm_flux[2] = {};          // the top-face fluxes of the prescribed atmosphere: heat, water (FT[ncols])
     double* d_math_tab = nullptr;      // log2/exp2 tables of MathFast<double>
+    char* h_ring = nullptr;            // pinned staging ring of lh_upload_profile (asynchronous small uploads)
+    size_t ring_bytes = 0, ring_pos = 0;
     lh_state* scratch_u1 = nullptr;    // SSPRK33 stage state
     lh_state* scratch_u2 = nullptr;    // second stage state (level-segmented launches cannot update U1 in place)
     lh_state* scratch_k1 = nullptr;    // f(Y) of lh_step_ssprk33_adaptive
@@ -417,6 +429,51 @@ Planes<FT> planes_of(const lh_state* s) {
     return p;
 }
 
+// the zero bit of a plane the library has just filled with zeros (never for an exposed plane)
+void mark_zero(lh_state* s, int var) {
+    if (!(s->exposed_mask & (1u << var))) s->zero_mask |= 1u << var;
+}
+// a plane is about to be (or may have been) overwritten with arbitrary values
+void mark_written(lh_state* s, uint32_t vars) {
+    s->zero_mask &= ~vars;
+    s->profile_mask &= ~vars;
+    s->stale_mask &= ~vars;
+}
+
+// Give the planes of `vars` the values of their level-uniform profiles (one broadcast launch per
+// stale plane); the profile stays valid.  Every consumer that addresses planes calls this first.
+int materialize(lh_ctx* c, const lh_state* cs, uint32_t vars) {
+    lh_state* s = const_cast<lh_state*>(cs);
+    if (!s) return LH_OK;
+    const uint32_t todo = s->stale_mask & s->profile_mask & vars;
+    for (int i = 0; i < LH_NVARS && todo; ++i)
+        if (todo >> i & 1u) {
+            if (c->cfg.dtype == LH_F64)
+                launch_broadcast_profile<double>(static_cast<double*>(s->plane[i]), static_cast<const double*>(s->profile[i]),
+                                                 c->cfg.ncols, c->stride, c->cfg.nlev, c->stream);
+            else
+                launch_broadcast_profile<float>(static_cast<float*>(s->plane[i]), static_cast<const float*>(s->profile[i]),
+                                                c->cfg.ncols, c->stride, c->cfg.nlev, c->stream);
+            LH_HIP(c, hipGetLastError());
+        }
+    s->stale_mask &= ~todo;
+    return LH_OK;
+}
+
+// the variables of Ya a column launch takes from a level-uniform profile instead of a plane
+uint32_t aux_profile_vars(const lh_ctx* c, const lh_state* aux) {
+    if (!aux) return 0;
+    uint32_t m = 0;
+    if (c->cfg.model == LH_MODEL_HEAT) m = LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_THETA_I);
+    else if (c->cfg.model == LH_MODEL_RICHARDS) m = LH_MASK(LH_VAR_T);
+    return m & aux->profile_mask;
+}
+template <typename FT>
+void set_aux_profiles(const lh_ctx* c, const lh_state* aux, DevParams<FT>& P) {
+    const uint32_t m = aux_profile_vars(c, aux);
+    for (int i = 0; i < LH_NVARS; ++i) P.aux_prof[i] = (m >> i & 1u) ? static_cast<const FT*>(aux->profile[i]) : nullptr;
+}
+
 template <typename FT>
 int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
            double dt, int mode, const double* bc_override, const void* dt_device = nullptr,
@@ -424,6 +481,13 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
     DevParams<FT> P = make_params<FT>(c);
     if (unsegmented) P.seg_len = 0; // an in-place stage must not be level-segmented
     P.dt_out = dt_out;
+    {   // level-uniform variables: Ya's prescribed profiles go to the kernel as they are, the rest become planes
+        int rc;
+        if ((rc = materialize(c, in, ~0u)) || (rc = materialize(c, base, ~0u)) || (rc = materialize(c, out, ~0u)) ||
+            (rc = materialize(c, aux, ~aux_profile_vars(c, aux))))
+            return rc;
+        set_aux_profiles<FT>(c, aux, P);
+    }
     P.xcd_remap = c->tune.xcd;
     if (bc_override)
         for (int f = 0; f < 2; ++f)
@@ -456,14 +520,15 @@ int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* b
     if (tend && water && (c->tune.zero == 0 || !(out->zero_mask & ti_bit))) {
         const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
         LH_HIP(c, hipMemsetAsync(out->plane[LH_VAR_THETA_I], 0, bytes, c->stream));
-        out->zero_mask |= ti_bit;
+        mark_written(out, ti_bit);
+        mark_zero(out, LH_VAR_THETA_I);
     }
     launch_rhs<FT>(P, planes_of<FT>(in), planes_of<FT>(aux), planes_of<FT>(base), planes_of<FT>(out),
                    FT(dt), static_cast<const FT*>(dt_device), mode, factors, any_percol(c), noice, c->math, c->tune, c->stream);
     LH_HIP(c, hipGetLastError());
     // what the launch wrote: vartheta_l / rhoe_int values
-    if (water) out->zero_mask &= ~LH_MASK(LH_VAR_VARTHETA_L);
-    if (model_heat(c->cfg.model)) out->zero_mask &= ~LH_MASK(LH_VAR_RHOE_INT);
+    if (water) mark_written(out, LH_MASK(LH_VAR_VARTHETA_L));
+    if (model_heat(c->cfg.model)) mark_written(out, LH_MASK(LH_VAR_RHOE_INT));
     return LH_OK;
 }
 
@@ -521,6 +586,8 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
     s->ctx = c;
     s->mask = mask;
     s->zero_mask = mask; // every plane is cleared below
+    s->exposed_mask = s->profile_mask = s->stale_mask = 0;
+    for (int i = 0; i < LH_NVARS; ++i) s->profile[i] = nullptr;
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
     for (int i = 0; i < LH_NVARS; ++i) s->plane[i] = nullptr;
     for (int i = 0; i < LH_NVARS; ++i) {
@@ -547,8 +614,10 @@ int state_alloc(lh_ctx* c, uint32_t mask, lh_state** out) {
 }
 
 void state_free(lh_ctx* c, lh_state* s) {
-    for (int i = 0; i < LH_NVARS; ++i)
+    for (int i = 0; i < LH_NVARS; ++i) {
         if (s->plane[i]) plane_free(c, s->plane[i]);
+        if (s->profile[i]) (void)hipFree(s->profile[i]);
+    }
     for (size_t i = 0; i < c->states.size(); ++i)
         if (c->states[i] == s) {
             c->states.erase(c->states.begin() + i);
@@ -602,18 +671,24 @@ int run_column_stepper(lh_ctx* c, lh_state* Y, const lh_state* Ya, double dt, co
     const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
     const lh_state* ti_src = c->cfg.model == LH_MODEL_HEAT ? Ya : Y;
     const bool noice = c->tune.zero != 0 && !factors && ti_src && (ti_src->zero_mask & LH_MASK(LH_VAR_THETA_I));
+    {
+        int rc;
+        if ((rc = materialize(c, Y, ~0u)) || (rc = materialize(c, Ya, ~aux_profile_vars(c, Ya)))) return rc;
+    }
     if (c->cfg.dtype == LH_F64) {
         DevParams<double> P = make_params<double>(c);
+        set_aux_profiles<double>(c, Ya, P);
         launch_column_stepper<double>(P, planes_of<double>(Y), planes_of<double>(Ya), dt,
                                       static_cast<const double*>(dt_device), nsteps,
                                       static_cast<const double*>(d_bcv), factors, any_percol(c), noice, c->stream);
     } else {
         DevParams<float> P = make_params<float>(c);
+        set_aux_profiles<float>(c, Ya, P);
         launch_column_stepper<float>(P, planes_of<float>(Y), planes_of<float>(Ya), float(dt),
                                      static_cast<const float*>(dt_device), nsteps,
                                      static_cast<const float*>(d_bcv), factors, any_percol(c), noice, c->stream);
     }
-    Y->zero_mask &= ~(LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_RHOE_INT));
+    mark_written(Y, LH_MASK(LH_VAR_VARTHETA_L) | LH_MASK(LH_VAR_RHOE_INT));
     hipError_t e = hipGetLastError();
     if (d_bcv) { // the launch reads it: wait before releasing
         const hipError_t e2 = hipStreamSynchronize(c->stream);
@@ -940,6 +1015,7 @@ int lh_destroy(lh_ctx* c) {
     for (int k = 0; k < 2; ++k)
         if (c->d_atm_flux[k]) (void)hipFree(c->d_atm_flux[k]);
     if (c->d_math_tab) (void)hipFree(c->d_math_tab);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1142,7 +1218,11 @@ static int transfer(lh_ctx* c, lh_state* s, int32_t var, void* host, int64_t ls,
     if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
     if (ls < 1 || cs < 1) return fail(c, LH_EINVAL, "strides must be >= 1");
     (void)hipSetDevice(c->device);
-    if (upload) s->zero_mask &= ~(1u << var);
+    if (upload) mark_written(s, 1u << var);
+    else {
+        int rc = materialize(c, s, 1u << var);
+        if (rc) return rc;
+    }
     const int64_t ncols = c->cfg.ncols;
     const int nlev = c->cfg.nlev;
     const size_t es = c->esize;
@@ -1191,6 +1271,10 @@ int lh_download_level(lh_ctx* c, const lh_state* s, int32_t var, int32_t level, 
     if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
     if (level < 0 || level >= c->cfg.nlev) return fail(c, LH_EINVAL, "lh_download_level: level %d outside [0, %d)", level, c->cfg.nlev);
     (void)hipSetDevice(c->device);
+    {
+        int rc = materialize(c, s, 1u << var);
+        if (rc) return rc;
+    }
     // a level of a plane is one contiguous row of ncols elements
     const char* row = static_cast<const char*>(s->plane[var]) + size_t(level) * size_t(c->stride) * c->esize;
     LH_HIP(c, hipMemcpyAsync(host, row, size_t(c->cfg.ncols) * c->esize, hipMemcpyDeviceToHost, c->stream));
@@ -1207,8 +1291,8 @@ int lh_state_fill(lh_ctx* c, lh_state* s, int32_t var, double value) {
     if (c->cfg.dtype == LH_F64) launch_fill<double>(static_cast<double*>(s->plane[var]), n, value, c->stream);
     else launch_fill<float>(static_cast<float*>(s->plane[var]), n, float(value), c->stream);
     LH_HIP(c, hipGetLastError());
-    if (value == 0.0 && !std::signbit(value)) s->zero_mask |= 1u << var;
-    else s->zero_mask &= ~(1u << var);
+    mark_written(s, 1u << var);
+    if (value == 0.0 && !std::signbit(value)) mark_zero(s, var);
     return LH_OK;
 }
 
@@ -1218,10 +1302,13 @@ int lh_state_copy(lh_ctx* c, lh_state* dst, const lh_state* src) {
     if ((dst->mask & src->mask) != src->mask) return fail(c, LH_ESTATE, "lh_state_copy: destination lacks planes of the source");
     (void)hipSetDevice(c->device);
     const size_t bytes = size_t(c->cfg.nlev) * size_t(c->stride) * c->esize;
+    int rc = materialize(c, src, ~0u); // (the copy carries planes, not profiles)
+    if (rc) return rc;
     for (int i = 0; i < LH_NVARS; ++i)
         if (src->mask & (1u << i)) {
             LH_HIP(c, hipMemcpyAsync(dst->plane[i], src->plane[i], bytes, hipMemcpyDeviceToDevice, c->stream));
-            dst->zero_mask = (dst->zero_mask & ~(1u << i)) | (src->zero_mask & (1u << i));
+            mark_written(dst, 1u << i);
+            if (src->zero_mask & (1u << i)) mark_zero(dst, i);
         }
     return LH_OK;
 }
@@ -1229,10 +1316,62 @@ int lh_state_copy(lh_ctx* c, lh_state* dst, const lh_state* src) {
 int lh_state_device_ptr(lh_ctx* c, const lh_state* s, int32_t var, void** dptr, int64_t* ls, int64_t* cs) {
     if (!c || !s || !dptr) return fail(c, LH_EINVAL, "lh_state_device_ptr: NULL argument");
     if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    (void)hipSetDevice(c->device);
+    {
+        int rc = materialize(c, s, 1u << var);
+        if (rc) return rc;
+    }
     *dptr = s->plane[var];
-    const_cast<lh_state*>(s)->zero_mask &= ~(1u << var); // the caller may write through the pointer
+    // the caller may write through the pointer, now or later: nothing is assumed about this plane
+    // until lh_state_release_ptr
+    mark_written(const_cast<lh_state*>(s), 1u << var);
+    const_cast<lh_state*>(s)->exposed_mask |= 1u << var;
     if (ls) *ls = c->stride;
     if (cs) *cs = 1;
+    return LH_OK;
+}
+
+int lh_state_release_ptr(lh_ctx* c, lh_state* s, int32_t var) {
+    if (!c || !s) return fail(c, LH_EINVAL, "lh_state_release_ptr: NULL argument");
+    if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if (var < -1 || var >= LH_NVARS) return fail(c, LH_EINVAL, "lh_state_release_ptr: bad variable %d", var);
+    s->exposed_mask &= var < 0 ? 0u : ~(1u << var);
+    return LH_OK;
+}
+
+int lh_upload_profile(lh_ctx* c, lh_state* s, int32_t var, const void* host) {
+    if (!c || !s || !host) return fail(c, LH_EINVAL, "lh_upload_profile: NULL argument");
+    if (s->ctx != c) return fail(c, LH_EINVAL, "state belongs to another context");
+    if (var < 0 || var >= LH_NVARS || !(s->mask & (1u << var))) return fail(c, LH_ESTATE, "state has no variable %d", var);
+    (void)hipSetDevice(c->device);
+    const int nlev = c->cfg.nlev;
+    const size_t bytes = size_t(nlev) * c->esize;
+    {   // an all-(+0) profile is a zero fill: the plane is then KNOWN to be zero (no ice: not even read)
+        bool allzero = true;
+        const unsigned char* b = static_cast<const unsigned char*>(host);
+        for (size_t k = 0; k < bytes && allzero; ++k) allzero = b[k] == 0;
+        if (allzero) return lh_state_fill(c, s, var, 0.0);
+    }
+    if (!s->profile[var]) LH_HIP(c, hipMalloc(&s->profile[var], bytes));
+    // through a pinned staging ring, so that the copy is asynchronous and the call returns at once
+    // (a time-dependent prescribed profile is refreshed at every stage: three uploads per step)
+    if (!c->h_ring) {
+        c->ring_bytes = size_t(1) << 18;
+        if (c->ring_bytes < 4 * bytes) c->ring_bytes = 4 * bytes;
+        LH_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_ring), c->ring_bytes, hipHostMallocDefault));
+        c->ring_pos = 0;
+    }
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (c->ring_pos + need > c->ring_bytes) { // wrap: every earlier copy out of the ring must have completed
+        LH_HIP(c, hipStreamSynchronize(c->stream));
+        c->ring_pos = 0;
+    }
+    memcpy(c->h_ring + c->ring_pos, host, bytes);
+    LH_HIP(c, hipMemcpyAsync(s->profile[var], c->h_ring + c->ring_pos, bytes, hipMemcpyHostToDevice, c->stream));
+    c->ring_pos += need;
+    mark_written(s, 1u << var);
+    s->profile_mask |= 1u << var;
+    s->stale_mask |= 1u << var;
     return LH_OK;
 }
 
@@ -1284,6 +1423,7 @@ int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* o
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     if ((rc = check_state(c, out, 0xFu, "diagnostic"))) return rc;
     (void)hipSetDevice(c->device);
+    if ((rc = materialize(c, Y, ~0u)) || (rc = materialize(c, Ya, ~0u))) return rc;
     if (c->cfg.dtype == LH_F64) {
         DevParams<double> P = make_params<double>(c);
         launch_diag<double>(P, planes_of<double>(Y), planes_of<double>(Ya), planes_of<double>(out), any_percol(c), c->math, c->stream);
@@ -1292,7 +1432,7 @@ int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* o
         launch_diag<float>(P, planes_of<float>(Y), planes_of<float>(Ya), planes_of<float>(out), any_percol(c), c->math, c->stream);
     }
     LH_HIP(c, hipGetLastError());
-    out->zero_mask = 0;
+    mark_written(out, ~0u);
     return LH_OK;
 }
 
@@ -1440,8 +1580,8 @@ int lh_step_ssprk33_adaptive(lh_ctx* c, lh_state* Y, const lh_state* Ya, double 
                  : do_rhs<float>(c, Y, Ya, nullptr, K1, courant, 4, nullptr, nullptr, dt_device_ft);
         if (rc) return rc;
         if ((rc = allreduce_min(c, dt_device_ft))) return rc;
-        if (f64) launch_dt_prepare<double>(static_cast<double*>(dt_device_ft), dt_max, static_cast<double*>(elapsed_device_ft), c->stream);
-        else launch_dt_prepare<float>(static_cast<float*>(dt_device_ft), float(dt_max), static_cast<float*>(elapsed_device_ft), c->stream);
+        if (f64) launch_dt_prepare<double>(static_cast<double*>(dt_device_ft), dt_max, static_cast<double*>(elapsed_device_ft), c->d_status, c->stream);
+        else launch_dt_prepare<float>(static_cast<float*>(dt_device_ft), float(dt_max), static_cast<float*>(elapsed_device_ft), c->d_status, c->stream);
         if (three) {
             // stage 2 from (Y, k1): U1 = Y + dt k1 formed in registers; then stage 3
             rc = f64 ? do_rhs<double>(c, K1, Ya, Y, U1, 0.0, 5, nullptr, dt_device_ft)
@@ -1472,6 +1612,7 @@ int lh_stable_dt_device(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double
     if ((rc = check_state(c, Y, prognostic_mask(c->cfg.model), "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
+    if ((rc = materialize(c, Y, ~0u)) || (rc = materialize(c, Ya, ~0u))) return rc;
     if (c->cfg.dtype == LH_F64) {
         DevParams<double> P = make_params<double>(c);
         launch_stable_dt<double>(P, planes_of<double>(Y), planes_of<double>(Ya), courant, d_out, any_percol(c), c->stream);
@@ -1529,6 +1670,7 @@ int lh_tune_placement(lh_ctx* c, lh_state* Y, const lh_state* Ya, lh_state* dY, 
     if (dY == Y) return fail(c, LH_EINVAL, "lh_tune_placement: dY must not be Y");
     if (flags & ~uint32_t(LH_PLACE_MOVE_INPUT)) return fail(c, LH_EINVAL, "lh_tune_placement: unknown flag bits");
     (void)hipSetDevice(c->device);
+    if ((rc = materialize(c, Y, ~0u)) || (rc = materialize(c, Ya, ~0u)) || (rc = materialize(c, dY, ~0u))) return rc;
     const bool f64 = c->cfg.dtype == LH_F64;
     lh_state* written = dY;
     if (!dY && (use_column_stepper(c, 1) || segment_length(c) > 0)) { // no stage state in HBM, or a cache-resident one
@@ -1647,6 +1789,10 @@ int lh_stream_probe(lh_ctx* c, const lh_state* in, uint32_t read_mask, lh_state*
         return fail(c, LH_ESTATE, "lh_stream_probe: a selected plane does not exist");
     if (reps < 1) reps = 20;
     (void)hipSetDevice(c->device);
+    {
+        int rc;
+        if ((rc = materialize(c, in, read_mask)) || (rc = materialize(c, out, write_mask))) return rc;
+    }
     // the selected planes, packed to the front
     void *rp[4] = {nullptr, nullptr, nullptr, nullptr}, *wp[4] = {nullptr, nullptr, nullptr, nullptr};
     int nr = 0, nw = 0;
@@ -1667,7 +1813,7 @@ int lh_stream_probe(lh_ctx* c, const lh_state* in, uint32_t read_mask, lh_state*
             launch_stream_probe<float>(c->cfg.ncols, c->stride, c->cfg.nlev, c->tune.xcd, pi, nr, po, nw, nt, c->stream);
         }
     };
-    out->zero_mask &= ~write_mask;
+    mark_written(out, write_mask);
     for (int r = 0; r < 3; ++r) go();
     LH_HIP(c, hipGetLastError());
     LH_HIP(c, hipEventRecord(c->ev0, c->stream));

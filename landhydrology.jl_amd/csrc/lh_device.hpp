@@ -84,6 +84,10 @@ struct DevParams {
     int32_t cs_cpb;         // persistent column stepper: columns per workgroup (0 = launcher's choice)
     int32_t seg_len;        // > 0: level-segmented launch, levels per segment (small ensembles)
     int32_t xcd_remap;      // workgroup -> column-block map that gives each XCD one contiguous column range
+    // LEVEL-UNIFORM prescribed fields of Ya (lh_upload_profile): FT[nlev] device arrays or nullptr, indexed
+    // like Planes::v -- the column kernels stage them in LDS beside z and read no plane for them
+    // (Ya.soil.T .= T_profile.(zc, t) is a function of z and t only: right_hand_side.jl:54-62)
+    const FT* aux_prof[4];
     int32_t vg_fast_all;    // every column has ColC::vg_fast (host decision: uniform parameters + the ranges of the per-column arrays)
 };
 

@@ -304,6 +304,21 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // neutral 0 there
     float* s_red = reinterpret_cast<float*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
     if (WANT_DT) s_red[threadIdx.x] = 0.0f;
+    // level-uniform prescribed fields of Ya (DevParams::aux_prof), staged behind z and the reduction
+    // words: T for the Richards viscosity factor, vartheta_l and theta_i for the heat-only model
+    constexpr bool MAY_PROF = (MODEL == MODEL_HEAT) || (MODEL == MODEL_RICHARDS && FACTORS);
+    FT* s_pf = reinterpret_cast<FT*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)) +
+                                     (WANT_DT ? ((size_t(blockDim.x) * sizeof(float) + 15) & ~size_t(15)) : 0));
+    const FT* pf_T = (MAY_PROF && MODEL == MODEL_RICHARDS) ? P.aux_prof[3] : nullptr;
+    const FT* pf_vl = (MAY_PROF && MODEL == MODEL_HEAT) ? P.aux_prof[0] : nullptr;
+    const FT* pf_ti = (MAY_PROF && MODEL == MODEL_HEAT) ? P.aux_prof[1] : nullptr;
+    if constexpr (MAY_PROF) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (pf_T) s_pf[i] = pf_T[i];
+            if (pf_vl) s_pf[i] = pf_vl[i];
+            if (pf_ti) s_pf[n + i] = pf_ti[i];
+        }
+    }
     const M mm(stage_math_tables<M>(P.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
 
@@ -416,11 +431,26 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     }
     // loads the level the row pointers currently address into ring slot `slot`,
     // then moves the pointers one level up
+    int lev_f = i_first; // the level fetch() addresses
     auto fetch = [&](int slot) {
-        rload(r_vl, vl_n[slot]);
-        if (!NOICE) rload(r_ti, ti_n[slot]);
+        if (MAY_PROF && pf_vl) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) vl_n[slot][j] = s_pf[lev_f];
+        } else rload(r_vl, vl_n[slot]);
+        if (!NOICE) {
+            if (MAY_PROF && pf_ti) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) ti_n[slot][j] = s_pf[n + lev_f];
+            } else rload(r_ti, ti_n[slot]);
+        }
         if (HEAT) rload(r_re, re_n[slot]);
-        if (need_Taux) rload(r_Ta, Ta_n[slot]);
+        if (need_Taux) {
+            if (MAY_PROF && pf_T) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) Ta_n[slot][j] = s_pf[lev_f];
+            } else rload(r_Ta, Ta_n[slot]);
+        }
+        ++lev_f;
         if (FROM_K1 && WATER) { rload(r_k1v, kv_n[slot]); r_k1v += stride; }
         if (FROM_K1 && HEAT) { rload(r_k1e, ke_n[slot]); r_k1e += stride; }
         r_vl += stride;
@@ -752,16 +782,20 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
         }
     };
     auto fetched = [&](int k) -> FT { return (col_raw < P.ncols) ? tiles[k * tile_n + slot * n + ic] : FT(0); };
-    // HEAT reads the prescribed water fields from Ya (right_hand_side.jl:200-201)
-    request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
-    if (!NOICE) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
+    // HEAT reads the prescribed water fields from Ya (right_hand_side.jl:200-201); level-uniform
+    // prescribed fields (DevParams::aux_prof) come from their [nlev] arrays, not from planes
+    const FT* pf_vl = MODEL == MODEL_HEAT ? P.aux_prof[0] : nullptr;
+    const FT* pf_ti = MODEL == MODEL_HEAT ? P.aux_prof[1] : nullptr;
+    const FT* pf_T = need_Taux ? P.aux_prof[3] : nullptr;
+    if (!pf_vl) request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
+    if (!NOICE && !pf_ti) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
     if (HEAT) request(Y.v[2], 2);
-    if (need_Taux) request(AUX.v[3], 3);
+    if (need_Taux && !pf_T) request(AUX.v[3], 3);
     __syncthreads();
-    FT y_vl = fetched(0);
-    const FT ti = NOICE ? FT(0) : fetched(1); // NOICE: the theta_i plane is known to be all zeros
+    FT y_vl = pf_vl ? pf_vl[ic] : fetched(0);
+    const FT ti = NOICE ? FT(0) : (pf_ti ? pf_ti[ic] : fetched(1)); // NOICE: the theta_i plane is known to be all zeros
     FT y_re = HEAT ? fetched(2) : FT(0);
-    const FT Ta = need_Taux ? fetched(3) : FT(288);
+    const FT Ta = need_Taux ? (pf_T ? pf_T[ic] : fetched(3)) : FT(288);
     __syncthreads();
     const FT z = P.zc[ic];
     FT nf_acc = FT(0);
@@ -957,10 +991,14 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
             if (col_first + cs < P.ncols) tiles[k * tile_n + cs * n + lev] = plane[int64_t(lev) * P.stride + col_first + cs];
         }
     };
-    request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
-    if (!NOICE) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
+    // (level-uniform prescribed fields of Ya come from their [nlev] arrays: DevParams::aux_prof)
+    const FT* pf_vl = MODEL == MODEL_HEAT ? P.aux_prof[0] : nullptr;
+    const FT* pf_ti = MODEL == MODEL_HEAT ? P.aux_prof[1] : nullptr;
+    const FT* pf_T = need_Taux ? P.aux_prof[3] : nullptr;
+    if (!pf_vl) request(MODEL == MODEL_HEAT ? AUX.v[0] : Y.v[0], 0);
+    if (!NOICE && !pf_ti) request(MODEL == MODEL_HEAT ? AUX.v[1] : Y.v[1], 1);
     if (HEAT) request(Y.v[2], 2);
-    if (need_Taux) request(AUX.v[3], 3);
+    if (need_Taux && !pf_T) request(AUX.v[3], 3);
     __syncthreads();
     FT y_vl[CW], y_re[CW], ti[CW], Ta[CW], z[CW];
     bool act[CW]; // the cell exists (and the column does)
@@ -970,10 +1008,10 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
         const int ic = i < n ? i : n - 1;
         act[q] = i < n && col_raw < P.ncols;
         const bool have = col_raw < P.ncols;
-        y_vl[q] = have ? tiles[slot * n + ic] : FT(0);
-        ti[q] = (!NOICE && have) ? tiles[tile_n + slot * n + ic] : FT(0); // NOICE: the theta_i plane is known to be all zeros
+        y_vl[q] = pf_vl ? pf_vl[ic] : (have ? tiles[slot * n + ic] : FT(0));
+        ti[q] = NOICE ? FT(0) : (pf_ti ? pf_ti[ic] : (have ? tiles[tile_n + slot * n + ic] : FT(0))); // NOICE: the theta_i plane is known to be all zeros
         y_re[q] = (HEAT && have) ? tiles[2 * tile_n + slot * n + ic] : FT(0);
-        Ta[q] = (need_Taux && have) ? tiles[3 * tile_n + slot * n + ic] : FT(288);
+        Ta[q] = need_Taux ? (pf_T ? pf_T[ic] : (have ? tiles[3 * tile_n + slot * n + ic] : FT(288))) : FT(288);
         z[q] = P.zc[ic];
     }
     __syncthreads(); // the tiles overlay other columns' exchange arrays
@@ -1383,16 +1421,28 @@ __global__ void __launch_bounds__(256) fill_kernel(FT* p, int64_t n, FT v) {
 }
 
 template <typename FT>
+__global__ void __launch_bounds__(256) broadcast_profile_kernel(FT* plane, const FT* __restrict__ prof, int64_t ncols, int64_t stride) {
+    const int64_t col = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (col < ncols) plane[int64_t(blockIdx.y) * stride + col] = prof[blockIdx.y];
+}
+
+template <typename FT>
 __global__ void __launch_bounds__(256) convert_kernel(FT* dst, const double* src, int64_t n) {
     int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = FT(src[i]);
 }
 
-// one thread: dt = min(dt, dt_max) (dt_max <= 0: no cap), elapsed += dt
+// one thread: dt = min(dt, dt_max) (dt_max <= 0: no cap), elapsed += dt.  A bound that is not a
+// positive finite number (no positive diffusivity anywhere and no cap: +inf; a NaN) would turn the
+// state into NaNs: the step is then taken with dt = 0 (the state stays) and bit 2 of the status is set.
 template <typename FT>
-__global__ void dt_prepare_kernel(FT* dt, FT dt_max, FT* elapsed) {
+__global__ void dt_prepare_kernel(FT* dt, FT dt_max, FT* elapsed, uint32_t* status) {
     FT d = *dt;
-    if (dt_max > FT(0) && d > dt_max) d = dt_max;
+    if (dt_max > FT(0) && !(d <= dt_max)) d = dt_max;
+    if (!(d > FT(0)) || d - d != FT(0)) {
+        d = FT(0);
+        atomicOr(status, 4u);
+    }
     *dt = d;
     if (elapsed) *elapsed += d;
 }
@@ -1424,8 +1474,11 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
     dim3 g = grid_for(lanes, block), b(block);
     if (CFG::SEG) g.y = (unsigned)((P.nlev + P.seg_len - 1) / P.seg_len);
     // dynamic LDS: z_i, plus one word per thread for the mode-4 reduction
+    // (+ two level arrays for level-uniform prescribed fields of Ya where the kernel can take them)
+    constexpr bool MAY_PROF = (MODEL == MODEL_HEAT) || (MODEL == MODEL_RICHARDS && FACTORS);
     const unsigned dyn = (unsigned)((((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15) +
-                                    (mode == 4 ? (size_t)block * sizeof(FT) : 0));
+                                    (mode == 4 ? (((size_t)block * sizeof(float) + 15) & ~(size_t)15) : 0) +
+                                    (MAY_PROF ? 2 * (size_t)P.nlev * sizeof(FT) : 0));
     if constexpr (!M::is_production) { // MathLibm: tendency only (the other modes are never instantiated)
         hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, false>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
     } else {
@@ -1691,8 +1744,8 @@ void launch_stream_probe(int64_t ncols, int64_t stride, int nlev, int xcd_remap,
 }
 
 template <typename FT>
-void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, hipStream_t s) {
-    hipLaunchKernelGGL((dt_prepare_kernel<FT>), dim3(1), dim3(1), 0, s, dt, dt_max, elapsed);
+void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL((dt_prepare_kernel<FT>), dim3(1), dim3(1), 0, s, dt, dt_max, elapsed, status);
 }
 
 template <typename FT>
@@ -1701,6 +1754,12 @@ void launch_fill(FT* p, int64_t n, FT v, hipStream_t s) {
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((fill_kernel<FT>), dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+}
+
+template <typename FT>
+void launch_broadcast_profile(FT* plane, const FT* prof, int64_t ncols, int64_t stride, int nlev, hipStream_t s) {
+    dim3 g((unsigned)((ncols + 255) / 256), (unsigned)nlev);
+    hipLaunchKernelGGL((broadcast_profile_kernel<FT>), g, dim3(256), 0, s, plane, prof, ncols, stride);
 }
 
 template <typename FT>
@@ -1726,7 +1785,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
     template void launch_atmos_flux<FT>(const DevParams<FT>&, const AtmosParams<FT>&, int64_t, bool,  \
                                         bool, const FT*, const FT*, const FT*, FT*, FT*, hipStream_t); \
     template void launch_fill<FT>(FT*, int64_t, FT, hipStream_t);                                     \
-    template void launch_dt_prepare<FT>(FT*, FT, FT*, hipStream_t);                                   \
+    template void launch_broadcast_profile<FT>(FT*, const FT*, int64_t, int64_t, int, hipStream_t);   \
+    template void launch_dt_prepare<FT>(FT*, FT, FT*, uint32_t*, hipStream_t);                                   \
     template void launch_convert<FT>(FT*, const double*, int64_t, hipStream_t);
 
 } // namespace lh

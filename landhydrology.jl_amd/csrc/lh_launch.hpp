@@ -61,9 +61,12 @@ void launch_atmos_flux(const DevParams<FT>& P, const AtmosParams<FT>& A, int64_t
                        const FT* vl, const FT* ti, const FT* third, FT* out_heat, FT* out_water, hipStream_t s);
 template <typename FT>
 void launch_fill(FT* p, int64_t n, FT v, hipStream_t s);
+// plane[lev][col] = prof[lev]: a level-uniform variable made a plane (lh_upload_profile)
+template <typename FT>
+void launch_broadcast_profile(FT* plane, const FT* prof, int64_t ncols, int64_t stride, int nlev, hipStream_t s);
 // one thread: dt = min(dt, dt_max), elapsed += dt (lh_step_ssprk33_adaptive)
 template <typename FT>
-void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, hipStream_t s);
+void launch_dt_prepare(FT* dt, FT dt_max, FT* elapsed, uint32_t* status, hipStream_t s);
 template <typename FT>
 void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s);
 

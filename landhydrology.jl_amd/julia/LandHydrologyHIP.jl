@@ -220,6 +220,14 @@ function upload!(st::DeviceState, var::Symbol, A::AbstractMatrix{FT}) where {FT}
                             (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64),
                             st.ens.ctx, st.handle, LH_VAR[var], A, 1, size(A, 1)))
 end
+# one value per level, the same in every column (Ya.soil.T .= T_profile.(zc, t) is a function of z and t
+# only, right_hand_side.jl:54-62): nelements numbers cross PCIe, and the column kernels read a
+# level-uniform prescribed field from LDS instead of a plane
+function upload!(st::DeviceState, var::Symbol, v::AbstractVector{FT}) where {FT}
+    length(v) == st.ens.model.domain.nelements || error("a per-level profile has nelements values")
+    check(st.ens.ctx, ccall((:lh_upload_profile, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+                            st.ens.ctx, st.handle, LH_VAR[var], v))
+end
 function download!(A::AbstractMatrix{FT}, st::DeviceState, var::Symbol) where {FT}
     check(st.ens.ctx, ccall((:lh_download, lib), Cint,
                             (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64),
@@ -265,11 +273,11 @@ function aux_mask(model::SoilModel)
 end
 
 # the prescribed profiles at time t on the centre coordinates zc (a Vector), as [nelements, ncolumns]
-# matrices uploaded into the aux state Yad (every column the same profile: the reference's closures
-# are functions of (z, t) only)
+# per-level profiles uploaded into the aux state Yad (every column the same profile: the reference's
+# closures are functions of (z, t) only)
 function upload_aux!(ens::ColumnEnsemble, Yad::DeviceState, zc::AbstractVector{FT}, t) where {FT}
     m = ens.model
-    rep(v) = repeat(reshape(FT.(v), :, 1), 1, ens.ncolumns)
+    rep(v) = collect(FT, v)   # a per-level profile: upload!(::DeviceState, ::Symbol, ::AbstractVector)
     if m.hydrology_model isa PrescribedHydrologyModel
         upload!(Yad, :ϑ_l, rep(m.hydrology_model.ϑ_l_profile.(zc, t)))
         upload!(Yad, :θ_i, rep(m.hydrology_model.θ_i_profile.(zc, t)))

@@ -388,7 +388,13 @@ class FieldVector:
                                           float(a) if a.ndim == 0 else 0.0), self._be.ctx)
             return
         if a.ndim == 1:
-            a = np.broadcast_to(a, (d.ncolumns, d.nelements))
+            # one value per level, the same in every column (what the reference's profile closures
+            # and an initial condition f(z) give): nelements numbers cross PCIe, not a plane
+            if a.shape != (d.nelements,):
+                raise ValueError(f"expected shape {(d.nelements,)} for a per-level profile, got {a.shape}")
+            a = np.ascontiguousarray(a)
+            F.check(F.lib().lh_upload_profile(self._be.ctx, self.handle, _VAR[name], a.ctypes.data), self._be.ctx)
+            return
         if a.shape != (d.ncolumns, d.nelements):
             raise ValueError(f"expected shape {(d.ncolumns, d.nelements)}, got {a.shape}")
         a = np.ascontiguousarray(a)
@@ -404,10 +410,18 @@ class FieldVector:
         return o
 
     def device_ptr(self, name):
+        """Device pointer and element strides of one plane.  Until release_ptr the library assumes
+        nothing about that plane (the holder may write through the pointer at any time)."""
         p, ls, cs = C.c_void_p(), C.c_int64(), C.c_int64()
         F.check(F.lib().lh_state_device_ptr(self._be.ctx, self.handle, _VAR[name], C.byref(p),
                                             C.byref(ls), C.byref(cs)), self._be.ctx)
         return p.value, ls.value, cs.value
+
+    def release_ptr(self, name=None):
+        """The holder of device_ptr pointers promises not to write through them any more
+        (name None: every plane of this state)."""
+        F.check(F.lib().lh_state_release_ptr(self._be.ctx, self.handle, -1 if name is None else _VAR[name]),
+                self._be.ctx)
 
 
 # -------------------------------------------------------------------- model
@@ -415,6 +429,9 @@ class FieldVector:
 
 class _Backend:
     """One lh_ctx: the device-side image of a SoilModel."""
+
+    def device_index(self) -> int:
+        return self._device
 
     def __init__(self, model: "SoilModel", stream=None, device=-1):
         d = model.domain
@@ -431,8 +448,13 @@ class _Backend:
         self.kind = kind
         self.ctx = None
         self._keep = []
+        self._device = int(device)
         if kind is None:
             return
+        if self._device < 0:   # the current device, by number (buffers handed to the library live there)
+            import torch
+            self._device = int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
+            device = self._device
         cfg = F.lh_config(d.ncolumns, d.nelements, F.dtype_code(d.FT), float(d.zlim[0]),
                           float(d.zlim[1]), kind, device, stream)
         ctx = C.c_void_p()
@@ -827,22 +849,35 @@ def stable_dt(model: SoilModel, Y: "FieldVector", Ya=None, courant: float = 0.5)
 
 
 def step_adaptive(model: SoilModel, Y: "FieldVector", Ya=None, t: float = 0.0, courant: float = 0.5,
-                  nsteps: int = 1, dt_max: float = 0.0):
+                  nsteps: int = 1, dt_max: float = 0.0, profiles_constant: bool = False):
     """Build extension: `nsteps` adaptive SSPRK33 steps of `Y` with nothing leaving the device
     (lh_step_ssprk33_adaptive: per step the tendency and the stable-step bound in one launch, the
     min over ranks when a communicator is attached, stages 2 and 3 -- three evaluations of the
     right-hand side per step).  Boundary values are those of time `t` (constant over the call: a
     time-dependent Dirichlet closure needs the stage times, i.e. `Simulation` with a fixed dt).
+    The stage times of an adaptive step are not known in advance, so prescribed profiles the device
+    reads (T with a viscosity factor, the water fields of a heat-only model) cannot be probed for
+    time dependence: the caller states `profiles_constant=True` (they are then taken at time `t`).
     Returns (simulated time advanced, last dt)."""
-    if _time_dependent(model) or _aux_time_dependent(model, Ya, t, 1.0):
-        raise ValueError("step_adaptive needs boundary values and prescribed profiles that do not depend on time")
+    if _time_dependent(model):
+        raise ValueError("step_adaptive needs boundary values that do not depend on time")
+    if _device_reads_aux(model, Ya):
+        if not profiles_constant:
+            raise ValueError("step_adaptive: the device reads prescribed profiles whose time dependence cannot be "
+                             "probed at unknown stage times; pass profiles_constant=True if they do not depend on t")
+        make_update_aux(model.energy_model)(Ya, t)
+        make_update_aux(model.hydrology_model)(Ya, t)
     be = model._backend()
     L = F.lib()
     ya = Ya.handle if isinstance(Ya, FieldVector) else None
     be.set_bcs(model, t)
     import torch
     dtype = torch.float64 if np.dtype(model.domain.FT) == np.float64 else torch.float32
-    buf = torch.zeros(2, device="cuda", dtype=dtype)              # [dt, elapsed]
+    # [dt, elapsed] on the CONTEXT's device; the zero fill runs on torch's stream, the library on its
+    # own (non-blocking) one: the fill must have completed before the first `*elapsed += dt`
+    dev = torch.device("cuda", be.device_index())
+    buf = torch.zeros(2, device=dev, dtype=dtype)
+    torch.cuda.synchronize(dev)
     F.check(L.lh_step_ssprk33_adaptive(be.ctx, Y.handle, ya, float(t), float(courant), float(dt_max), int(nsteps),
                                        C.c_void_p(buf.data_ptr()),
                                        C.c_void_p(buf.data_ptr() + buf.element_size())), be.ctx)
@@ -906,13 +941,23 @@ def _time_dependent(model):
     return False
 
 
-def _aux_time_dependent(model, Ya, t, dt) -> bool:
-    """Do the prescribed profiles the DEVICE reads change between t and the next stage times?
-    (Probed by evaluating the user's closures -- they are opaque callables -- at t, t + dt/2 and
-    t + dt on the model's own centre coordinates.)"""
-    be = model._backend()
-    if not _aux_mask(be.kind, model) or not isinstance(Ya, FieldVector):
-        return False
+def _device_reads_aux(model, Ya) -> bool:
+    """Does the device read a prescribed profile of Ya (T with a viscosity factor; the water fields of
+    a heat-only model)?"""
+    return bool(_aux_mask(model._backend().kind, model)) and isinstance(Ya, FieldVector)
+
+
+_PROBE_STEPS = 4096   # stage times probed (and stepped) at a time: 3 closure calls per step
+
+
+def _aux_constant_over(model, Ya, t, dt, nsteps) -> bool:
+    """Are the prescribed profiles the DEVICE reads the same at EVERY stage time of the next `nsteps`
+    steps (t + k dt, t + k dt + dt, t + k dt + dt/2)?  The reference's rhs! re-evaluates them at every
+    stage time (right_hand_side.jl:37-42); the closures are opaque callables, so every one of those
+    times is probed on the model's own centre coordinates -- a profile that starts to change later
+    in the chunk (piecewise in t, hold-then-ramp) is seen."""
+    if not _device_reads_aux(model, Ya):
+        return True
     z = np.asarray(Ya.zc)
     fns = []
     if isinstance(model.energy_model, PrescribedTemperatureModel):
@@ -921,10 +966,12 @@ def _aux_time_dependent(model, Ya, t, dt) -> bool:
         fns += [model.hydrology_model.vartheta_l_profile, model.hydrology_model.theta_i_profile]
     for f in fns:
         a0 = np.asarray(f(z, t) + 0.0 * z)
-        for tt in (t + dt / 2, t + dt):
-            if not np.array_equal(a0, np.asarray(f(z, tt) + 0.0 * z)):
-                return True
-    return False
+        for k in range(int(nsteps)):
+            tk = t + k * dt
+            for tt in ((tk,) if k else ()) + (tk + dt, tk + dt / 2):
+                if not np.array_equal(a0, np.asarray(f(z, tt) + 0.0 * z)):
+                    return False
+    return True
 
 
 def _advance_refreshing_aux(sim: Simulation, nsteps: int):
@@ -962,8 +1009,19 @@ def _advance(sim: Simulation, nsteps: int):
     ya = it.p.handle if isinstance(it.p, FieldVector) else None
     if nsteps <= 0:
         return
-    if _aux_time_dependent(model, it.p, it.t, it.dt):
-        return _advance_refreshing_aux(sim, nsteps)
+    if _device_reads_aux(model, it.p):
+        # prescribed profiles on the device: every stage time of the chunk is probed; only a chunk
+        # over which they do not change runs with Ya frozen (the persistent stepper), any other
+        # refreshes Ya at every stage like the reference's rhs! does
+        if nsteps > _PROBE_STEPS:
+            done = 0
+            while done < nsteps:
+                k = min(_PROBE_STEPS, nsteps - done)
+                _advance(sim, k)
+                done += k
+            return
+        if not _aux_constant_over(model, it.p, it.t, it.dt, nsteps):
+            return _advance_refreshing_aux(sim, nsteps)
     if _aux_mask(be.kind, model) and isinstance(it.p, FieldVector):
         # constant-in-time profiles: still the values of THIS time (a user may have edited Ya)
         make_update_aux(model.energy_model)(it.p, it.t)

@@ -140,3 +140,63 @@ def test_zero_bits_follow_every_writer():
     # a case with real ice is untouched by all of this
     got = pc.run_gpu_rhs(case)
     pc.assert_tendencies_close(case, got, pc.run_oracle_rhs(case))
+
+
+def test_a_kept_device_pointer_stays_trusted_by_nobody():
+    """A zero-copy host keeps the pointer lh_state_device_ptr gave it.  Whatever the library writes
+    into that plane afterwards (a zero fill, a copy of a zero plane, the d theta_i = 0 clear), a
+    later write through the OLD pointer must be seen by the next launch -- the plane stays
+    'exposed' until lh_state_release_ptr; afterwards a zero fill is trusted again."""
+    import dataclasses
+    import torch
+    full = pc.make_case("c3_coupled_f64", ncols=130)
+    want = pc.run_oracle_rhs(full)
+    filled = dataclasses.replace(full, ti=np.full_like(full.ti, 0.03))
+    want_filled = pc.run_oracle_rhs(filled)
+    hip = _loaded_hip_runtime()
+    with pc.GpuModel(full) as g:
+        F = g.F
+        Y, Ya = g.prognostic_and_aux()
+        dY = g.state(0)
+        p, ls, cs = C.c_void_p(), C.c_int64(), C.c_int64()
+        F.check(g.L.lh_state_device_ptr(g.ctx, Y, F.LH_VAR_THETA_I, C.byref(p), C.byref(ls), C.byref(cs)), g.ctx)
+        n = full.om.nlev * ls.value
+        host = np.zeros((full.om.nlev, ls.value))
+        host[:, :full.ncols] = 0.03
+        t = torch.from_numpy(host.reshape(-1))
+
+        def write_through_old_pointer():
+            F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+            assert hip.hipMemcpy(C.c_void_p(p.value), C.c_void_p(t.data_ptr()), C.c_size_t(n * 8), 1) == 0
+
+        # pointer first, THEN a zero fill, then the write through the old pointer
+        F.check(g.L.lh_state_fill(g.ctx, Y, F.LH_VAR_THETA_I, 0.0), g.ctx)
+        g.rhs(Y, Ya, dY)
+        pc.assert_tendencies_close(full, g.tendencies(dY), want)
+        write_through_old_pointer()
+        g.rhs(Y, Ya, dY)
+        pc.assert_tendencies_close(filled, g.tendencies(dY), want_filled)
+        # the same after a copy of an all-zero state over it
+        Z = g.state(0)
+        F.check(g.L.lh_state_copy(g.ctx, Y, Z), g.ctx)
+        for var, a in ((F.LH_VAR_VARTHETA_L, full.vl), (F.LH_VAR_RHOE_INT, full.rhoe)):
+            g.upload(Y, var, a)
+        write_through_old_pointer()
+        g.rhs(Y, Ya, dY)
+        pc.assert_tendencies_close(filled, g.tendencies(dY), want_filled)
+        # an exposed d theta_i plane of a tendency state: dirtied through the pointer between two
+        # launches, it is zero again after each of them
+        q = C.c_void_p()
+        F.check(g.L.lh_state_device_ptr(g.ctx, dY, F.LH_VAR_THETA_I, C.byref(q), None, None), g.ctx)
+        for _ in range(2):
+            F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+            assert hip.hipMemcpy(C.c_void_p(q.value), C.c_void_p(t.data_ptr()), C.c_size_t(n * 8), 1) == 0
+            g.rhs(Y, Ya, dY)
+            assert not np.any(g.tendencies(dY)["ti"])
+        # released: a zero fill is trusted again (the launch no longer reads the plane, so even a
+        # -- now illegal -- write through the old pointer would go unseen: that is the contract)
+        F.check(g.L.lh_state_release_ptr(g.ctx, Y, F.LH_VAR_THETA_I), g.ctx)
+        F.check(g.L.lh_state_fill(g.ctx, Y, F.LH_VAR_THETA_I, 0.0), g.ctx)
+        g.rhs(Y, Ya, dY)
+        pc.assert_tendencies_close(full, g.tendencies(dY), want)
+        assert g.status() == 0
