@@ -29,9 +29,9 @@ Prints ONE JSON line on rank 0 (see the driver contract).  How to read its numbe
   roofline.traffic            HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC
                               passes of the SAME command line (profiles/pmc_traffic.json), else null
 
-tests/parity_cases.py supplies the synthetic-input generator (pure numpy) and the C-ABI
-harness (GpuModel); the CPU oracle under oracle/ is loaded and executed in the
-cpu_baseline leg only (tests/test_abi_cpu.py checks that input generation does not).
+The synthetic-input generator (pure numpy) and the C-ABI driver (GpuModel) are part of the package
+(landhydrology.jl_amd/workloads.py): nothing under tests/ is imported.  The CPU oracle under oracle/
+is loaded and executed in the cpu_baseline leg only (tests/test_abi_cpu.py checks both).
 """
 import argparse
 import ctypes as C
@@ -44,7 +44,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy
 
@@ -78,7 +77,7 @@ def parse():
 
 
 WORKLOADS = {
-    # name -> (case name in tests/parity_cases.py, algorithmic bytes per cell-update, dtype tag)
+    # name -> (case name of workloads.make_case, algorithmic bytes per cell-update, dtype tag)
     "c2": ("c2_richards_f64", 32.0, "f64"),
     "c3": ("c3_coupled_f32", 24.0, "f32"),
     "c4": ("c4_richards_f64_128", 32.0, "f64"),
@@ -89,15 +88,18 @@ WORKLOADS = {
     "f3c32": ("mixed_smooth_f32", 24.0, "f32"),
     "f3c64": ("mixed_smooth_f64", 48.0, "f64"),
     "f3v64": ("richards_viscosity_f64", 40.0, "f64"),
+    # ... and with the prescribed temperature level-uniform, as the reference's T_profile(z, t) is:
+    # nlev numbers (lh_upload_profile), read from LDS -- no T plane is streamed
+    "f3v64p": ("richards_viscosity_profile_f64", 32.0, "f64"),
 }
 
 
 def build_case(workload, ncols, col_offset):
     """Synthetic inputs, generated chunk-wise on the host (counter-based hash, so
     every rank builds exactly its own block of the global ensemble)."""
-    import parity_cases as pc
+    import __graft_entry__ as g
     name = WORKLOADS[workload][0]
-    return pc.make_case(name, ncols=ncols, col_offset=col_offset)
+    return g.load_package().workloads.make_case(name, ncols=ncols, col_offset=col_offset)
 
 
 def _usable_cores():
@@ -134,7 +136,7 @@ def cpu_baseline(case, seconds):
     import dataclasses
     sys.path.insert(0, os.path.join(ROOT, "oracle"))     # the checker: this leg only
     import oracle_py as O
-    import parity_cases as pc
+    oracle_rhs = lambda c, nthreads: O.rhs(c.om, c.vl, c.ti, c.rhoe, c.T_aux, nthreads=nthreads)
     cores = _usable_cores()
     threads = max(1, min(cores, O.max_threads()))
     n = case.om.nlev
@@ -146,10 +148,10 @@ def cpu_baseline(case, seconds):
                                  percol_bc={k: v[:sample] for k, v in om.percol_bc.items()})
     sub = dataclasses.replace(case, om=om, ncols=sample, vl=sl(case.vl), ti=sl(case.ti),
                               rhoe=sl(case.rhoe), T_aux=sl(case.T_aux))
-    pc.run_oracle_rhs(sub, nthreads=threads)            # warm
+    oracle_rhs(sub, threads)            # warm
     reps, t0 = 0, time.perf_counter()
     while True:
-        pc.run_oracle_rhs(sub, nthreads=threads)
+        oracle_rhs(sub, threads)
         reps += 1
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 2000:
@@ -157,7 +159,7 @@ def cpu_baseline(case, seconds):
     # the same restatement on ONE thread (the reference has no threading): ~2 s of it
     r1, t1 = 0, time.perf_counter()
     while True:
-        pc.run_oracle_rhs(sub, nthreads=1)
+        oracle_rhs(sub, 1)
         r1 += 1
         el1 = time.perf_counter() - t1
         if el1 >= min(2.0, seconds) or r1 >= 50:
@@ -179,12 +181,13 @@ def planes_streamed(case):
     """(planes read, planes written, NOICE) by one tendency launch of this case: the prognostic
     planes of the model, minus a theta_i plane the library knows to be zero (kernels without
     conductivity factors), and never the identically zero d theta_i."""
-    import case_model as M
+    import __graft_entry__ as g
+    M = g.load_package().case_model
     om = case.om
     factors = bool(om.cf.viscosity_kind or om.cf.impedance_kind)
     noice = (case.ti is None or not case.ti.any()) and not factors
     if om.model == M.MODEL_RICHARDS:
-        nr = 1 + (0 if noice else 1) + (1 if om.cf.viscosity_kind else 0)
+        nr = 1 + (0 if noice else 1) + (1 if (om.cf.viscosity_kind and not case.aux_profile) else 0)   # a level-uniform T is no plane
         nw = 1
     elif om.model == M.MODEL_HEAT:
         nr, nw = 2 + (0 if noice else 1), 1
@@ -249,8 +252,8 @@ def main():
             dist.init_process_group("gloo")
 
     import __graft_entry__ as g
-    import parity_cases as pc
     pkg = g.load_package()
+    pc = pkg.workloads   # the synthetic cases and the C-ABI driver (nothing under tests/ is imported)
     F = pkg._ffi
 
     # weak scaling: rank r owns the block [r*ncols, (r+1)*ncols) of the global ensemble
@@ -355,7 +358,10 @@ def main():
         plain = d[np.arange(a.steps) % 3 != 2]
         fused = d[np.arange(a.steps) % 3 == 2]
         stats = {"ms_per_step_median": float(np.median(d)), "ms_per_step_min": float(d.min()),
-                 "ms_per_step_events_mean": float(d.mean())}
+                 "ms_per_step_events_mean": float(d.mean()),
+                 # the first steps of the timed loop one by one (every third is the fused-dt launch):
+                 # what a clock ramp or a slow box looks like from inside the run
+                 "per_step_ms": [round(float(x), 4) for x in d[:32]]}
         kern_ms, kern_n = float(plain.mean()), int(plain.size)
         kern_med, kern_min = float(np.median(plain)), float(plain.min())
         fused_ms = float(fused.mean()) if fused.size else None
@@ -396,6 +402,58 @@ def main():
                  "planes_read": len(rp), "planes_written": len(wp)}
     except Exception as e:      # noqa: BLE001
         probe = {"error": repr(e)}
+
+    # The SURVEY 8(d) byte contract as traffic: the same launch with the known-zero planes switched
+    # off (theta_i read, d theta_i = 0 stored: LH_TUNE zero=0), timed in THIS process right after
+    # the headline loop -- both byte regimes from one run, one box, one clock.
+    contract = None
+    if not a.no_known_zero:
+        try:
+            F.check(L.lh_set_tuning(ctx, b"zero=0"), ctx)
+            for _ in range(5):
+                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+            nk = max(10, min(a.steps, 60))
+            F.check(L.lh_timer_start(ctx), ctx)
+            for _ in range(nk):
+                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+            cms = C.c_float()
+            F.check(L.lh_timer_stop(ctx, C.byref(cms)), ctx)
+            c_ms = cms.value / nk
+            c_bytes = cells * bytes_per_cell
+            contract = {"kernel_ms": c_ms, "launches_timed": nk, "bytes_per_launch": c_bytes,
+                        "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "frac": c_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "is": "lh_rhs with LH_TUNE zero=0 (every prognostic plane read, every tendency plane "
+                              "written: the bytes of SURVEY 8(d)'s contract really moved), HIP events around a "
+                              "back-to-back block in this same process; the memset of the d theta_i plane is part of it"}
+        except Exception as e:      # noqa: BLE001
+            contract = {"error": repr(e)}
+        finally:
+            F.check(L.lh_set_tuning(ctx, b""), ctx)
+
+    # N > 1: what every rank measured, and what the one collective costs on its own (the in-stream
+    # min all-reduce of one FT value, timed by HIP events around a block of lh_allreduce_min calls)
+    ranks = None
+    if world > 1:
+        mine = torch.tensor([kern_ms, fused_ms if fused_ms is not None else float("nan"), ms_per_step],
+                            device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ar_ms = None
+        if native_comm:
+            for _ in range(5):
+                F.check(L.lh_allreduce_min(ctx, tdt.data_ptr()), ctx)
+            F.check(L.lh_timer_start(ctx), ctx)
+            for _ in range(50):
+                F.check(L.lh_allreduce_min(ctx, tdt.data_ptr()), ctx)
+            ams = C.c_float()
+            F.check(L.lh_timer_stop(ctx, C.byref(ams)), ctx)
+            ar_ms = ams.value / 50
+        ranks = {"kernel_ms": [float(x[0]) for x in allr], "fused_dt_kernel_ms": [float(x[1]) for x in allr],
+                 "ms_per_step": [float(x[2]) for x in allr],
+                 "allreduce_min_ms": ar_ms,
+                 "allreduce_share_of_a_3_eval_step": (ar_ms / (3 * kern_ms)) if ar_ms else None,
+                 "is": "per-rank HIP-event means of the timed loop (rank order); allreduce_min_ms: one "
+                       "ncclAllReduce(min, 1 value) on the launch stream, back-to-back block on rank 0"}
 
     # HBM bytes per launch from committed PMC passes of this same command line (rocprofv3 cannot
     # run inside the timed process): profiles/pmc_traffic.json, written by tools/gpu_profile.sh
@@ -458,6 +516,8 @@ def main():
                      "valu_is": "PROFILED (same committed PMC passes as traffic): VALU instructions per cell-update, and the "
                                 "fraction of the launch the SIMDs spend issuing them (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / "
                                 "GRBM_GUI_ACTIVE per XCD) -- the Float64 kernels are bound by this, not by HBM"},
+        "contract_traffic": contract,
+        "ranks": ranks,
         "stable_dt_seen": dt_seen,
         "placement_tuning": placement,
     }

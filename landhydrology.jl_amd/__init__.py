@@ -6,7 +6,7 @@ The directory name contains a dot, so it is loaded through
 `landhydrology_jl_amd`.  Compute lives in lib/liblandhydro_hip.so (HIP, gfx950);
 this package is the host-side mirror of the reference's Julia interface.
 """
-from . import _ffi, parameterizations, partition
+from . import _ffi, case_model, parameterizations, partition, workloads
 from ._ffi import LandHydroError, ModelError
 from .parameterizations import *  # noqa: F401,F403
 from .soil import (Column, Dirichlet, EarthParameterSet, FieldVector, Float32, Float64,

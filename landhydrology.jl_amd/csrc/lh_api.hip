@@ -7,6 +7,7 @@
 #include "lh_closures.hpp"
 
 #include <rccl/rccl.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -114,6 +115,15 @@ struct lh_ctx {
 
 namespace {
 
+// roctx range around one call of the path (rhs, stage, step, allreduce): what a rocprofv3
+// --marker-trace of a multi-GPU run is read by; a few tens of nanoseconds without a tool attached
+struct Range {
+    explicit Range(const char* name) { roctxRangePushA(name); }
+    ~Range() { roctxRangePop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
+
 int fail(lh_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -137,6 +147,7 @@ int fail(lh_ctx* ctx, int code, const char* fmt, ...) {
 // context's stream behind whatever produced the value (no host round trip).
 int allreduce_min(lh_ctx* c, void* value_device_ft) {
     if (!c->comm) return LH_OK;
+    Range r_("lh:allreduce_min");
     const ncclResult_t r = ncclAllReduce(value_device_ft, value_device_ft, 1,
                                          c->cfg.dtype == LH_F64 ? ncclDouble : ncclFloat, ncclMin, c->comm, c->stream);
     if (r != ncclSuccess) return fail(c, LH_ENODEVICE, "ncclAllReduce(min) failed: %s", ncclGetErrorString(r));
@@ -478,6 +489,8 @@ template <typename FT>
 int do_rhs(lh_ctx* c, const lh_state* in, const lh_state* aux, const lh_state* base, lh_state* out,
            double dt, int mode, const double* bc_override, const void* dt_device = nullptr,
            void* dt_out = nullptr, bool unsegmented = false) {
+    static const char* const range_names[6] = {"lh:rhs", "lh:stage1", "lh:stage2", "lh:stage3", "lh:rhs_stable_dt", "lh:stage2_from_k1"};
+    Range r_(range_names[mode >= 0 && mode < 6 ? mode : 0]);
     DevParams<FT> P = make_params<FT>(c);
     if (unsegmented) P.seg_len = 0; // an in-place stage must not be level-segmented
     P.dt_out = dt_out;
@@ -652,6 +665,7 @@ bool use_column_stepper(const lh_ctx* c, int64_t nsteps) {
 int run_column_stepper(lh_ctx* c, lh_state* Y, const lh_state* Ya, double dt, const void* dt_device,
                        int64_t nsteps, const double* bcv) {
     if (nsteps <= 0) return LH_OK;
+    Range r_("lh:column_stepper");
     void* d_bcv = nullptr;
     if (bcv) { // [nsteps][3][2][2] doubles -> FT on the device
         const size_t nv = size_t(nsteps) * 12;
@@ -1441,6 +1455,7 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     (void)t;
     if (!c) return LH_EINVAL;
     if (nsteps < 0 || !(dt > 0)) return fail(c, LH_EINVAL, "lh_step_ssprk33: need nsteps >= 0 and dt > 0");
+    Range r_("lh:step_ssprk33");
     int rc = validate_model(c);
     if (rc) return rc;
     const uint32_t pm = prognostic_mask(c->cfg.model);
@@ -1558,6 +1573,7 @@ int lh_step_ssprk33_adaptive(lh_ctx* c, lh_state* Y, const lh_state* Ya, double 
     (void)t;
     if (!c || !dt_device_ft) return fail(c, LH_EINVAL, "lh_step_ssprk33_adaptive: NULL argument");
     if (nsteps < 0 || !(courant > 0)) return fail(c, LH_EINVAL, "lh_step_ssprk33_adaptive: need nsteps >= 0 and courant > 0");
+    Range r_("lh:step_ssprk33_adaptive");
     int rc = validate_model(c);
     if (rc) return rc;
     const uint32_t pm = prognostic_mask(c->cfg.model);

@@ -110,8 +110,8 @@ def test_host_mirror_domain_and_errors(pkg):
 
 def test_bench_input_generation_executes_nothing_of_the_oracle():
     """bench.py may use the oracle in its cpu_baseline leg only: importing bench.py and building
-    the synthetic inputs of every workload must not even IMPORT anything from oracle/ (model
-    descriptions live in tests/case_model.py)."""
+    the synthetic inputs of every workload must not even IMPORT anything from oracle/ -- nor from
+    tests/ (the case generator and the C-ABI driver are package modules: workloads.py, case_model.py)."""
     import subprocess
     import sys
     code = (
@@ -123,6 +123,7 @@ def test_bench_input_generation_executes_nothing_of_the_oracle():
         "    assert c.vl is not None and c.vl.shape[0] == 300, w\n"
         "assert 'oracle_py' not in sys.modules, 'input generation imported the oracle binding'\n"
         "assert not any('oracle' in (getattr(m, '__file__', '') or '').split(os.sep) for m in list(sys.modules.values())), 'a module from oracle/ was imported'\n"
+        "assert not any('tests' in (getattr(m, '__file__', '') or '').split(os.sep) for m in list(sys.modules.values())), 'bench.py imported a module from tests/'\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)

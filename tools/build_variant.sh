@@ -14,6 +14,6 @@ for f in "$src"/*.hip; do
     /opt/rocm/bin/hipcc $flags "$@" -c "$f" -o "$tmp/$(basename "$f" .hip).o" &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$out/liblandhydro_hip_$name.so" "$tmp"/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$out/liblandhydro_hip_$name.so" "$tmp"/*.o -L/opt/rocm/lib -lrccl -lrocprofiler-sdk-roctx -Wl,-rpath,/opt/rocm/lib
 rm -rf "$tmp"
 echo "$out/liblandhydro_hip_$name.so"
