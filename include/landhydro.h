@@ -263,6 +263,17 @@ int lh_rhs(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* d
 int lh_rhs_stable_dt(lh_ctx*, double t, const lh_state* Y, const lh_state* Ya, lh_state* dY,
                      double courant, void* dt_device_ft);
 
+/* boundary_fluxes(X, bc::SoilComponentBC, face, model, cs, t) (boundary_conditions.jl:470-489; with a
+ * PrescribedAtmosForcing at the top: :516-533) for every column: the pair (f_rhoe_int, f_vartheta_l)
+ * of ONE face -- LH_FACE_BOTTOM or LH_FACE_TOP -- from the state of the cell next to it, positive in
+ * +z: exactly the two SetValue fluxes the tendency launch uses (same device functions, same bits), for
+ * callers that budget water and energy.  Boundary values are those of the last lh_set_bc (the host
+ * shim evaluates Dirichlet closures at t first, as for lh_rhs).  f_energy / f_water: ncols doubles
+ * each (either may be NULL); NaN where the component has no boundary condition (NoBC: `nothing` in
+ * the reference).  Synchronises. */
+int lh_boundary_fluxes(lh_ctx*, const lh_state* Y, const lh_state* Ya, double t, int32_t face,
+                       double* f_energy, double* f_water);
+
 /* centre fields K, psi, kappa, T of the same pointwise stage
  * (right_hand_side.jl:156-167, 291-314) into a 4-plane state (LH_DIAG_*) */
 int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "lh_coordinates": (C.c_int, [_P, _DP]),
     "lh_rhs": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "lh_rhs_stable_dt": (C.c_int, [_P, C.c_double, _P, _P, _P, C.c_double, _P]),
+    "lh_boundary_fluxes": (C.c_int, [_P, _P, _P, C.c_double, C.c_int32, _DP, _DP]),
     "lh_diagnostics": (C.c_int, [_P, _P, _P, _P]),
     "lh_step_ssprk33": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, _DP]),
     "lh_ssprk33_stage": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, _DP]),

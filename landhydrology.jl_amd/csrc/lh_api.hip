@@ -885,6 +885,45 @@ int tune_state_planes(lh_ctx* c, lh_state* target, uint32_t plane_mask, int max_
 
 } // namespace
 
+namespace {
+
+template <typename FT>
+int boundary_fluxes_impl(lh_ctx* c, const lh_state* Y, const lh_state* Ya, int32_t face, double* f_energy, double* f_water) {
+    const int64_t n = c->cfg.ncols;
+    FT* d_out = nullptr;
+    LH_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * 2 * sizeof(FT)));
+    DevParams<FT> P = make_params<FT>(c);
+    if (c->hp.atmos_on && face == LH_FACE_TOP) {
+        // boundary_fluxes(X, bc::PrescribedAtmosForcing, :top, ...) (:516-533), as do_rhs prepares it
+        const size_t top = size_t(c->cfg.nlev - 1) * size_t(c->stride);
+        launch_atmos_flux<FT>(P, make_atmos_params<FT>(c), n, true, any_percol(c),
+                              static_cast<const FT*>(Y->plane[LH_VAR_VARTHETA_L]) + top,
+                              static_cast<const FT*>(Y->plane[LH_VAR_THETA_I]) + top,
+                              static_cast<const FT*>(Y->plane[LH_VAR_RHOE_INT]) + top,
+                              static_cast<FT*>(c->d_atm_flux[0]), static_cast<FT*>(c->d_atm_flux[1]), c->stream);
+        P.bc_kind[LH_FACE_TOP][LH_COMP_ENERGY] = P.bc_kind[LH_FACE_TOP][LH_COMP_HYDROLOGY] = LH_BC_FLUX;
+        P.bc_pc[LH_FACE_TOP][LH_COMP_ENERGY] = static_cast<const FT*>(c->d_atm_flux[0]);
+        P.bc_pc[LH_FACE_TOP][LH_COMP_HYDROLOGY] = static_cast<const FT*>(c->d_atm_flux[1]);
+    }
+    const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    launch_boundary_fluxes<FT>(P, planes_of<FT>(Y), planes_of<FT>(Ya), face, d_out, d_out + n, factors, any_percol(c),
+                               c->math, c->stream);
+    hipError_t e = hipGetLastError();
+    std::vector<FT> h(size_t(n) * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(FT), hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, LH_ENODEVICE, "lh_boundary_fluxes failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    for (int64_t i = 0; i < n; ++i) {
+        if (f_energy) f_energy[i] = double(h[size_t(i)]);
+        if (f_water) f_water[i] = double(h[size_t(n + i)]);
+    }
+    return LH_OK;
+}
+
+} // namespace
+
 // ============================================================== C ABI
 
 extern "C" {
@@ -1426,6 +1465,23 @@ int lh_rhs_stable_dt(lh_ctx* c, double t, const lh_state* Y, const lh_state* Ya,
              : do_rhs<float>(c, Y, Ya, nullptr, dY, courant, 4, nullptr, nullptr, dt_device_ft);
     if (rc) return rc;
     return allreduce_min(c, dt_device_ft); // the global minimum when a communicator is attached
+}
+
+int lh_boundary_fluxes(lh_ctx* c, const lh_state* Y, const lh_state* Ya, double t, int32_t face, double* f_energy,
+                       double* f_water) {
+    (void)t; // boundary values of time t are set by the host shim (lh_set_bc) before the call, as for lh_rhs
+    if (!c) return LH_EINVAL;
+    if (face != LH_FACE_BOTTOM && face != LH_FACE_TOP) return fail(c, LH_EINVAL, "Expected :top or :bottom"); // boundary_conditions.jl:188
+    if (!f_energy && !f_water) return fail(c, LH_EINVAL, "lh_boundary_fluxes: both outputs are NULL");
+    int rc = validate_model(c);
+    if (rc) return rc;
+    if ((rc = check_state(c, Y, prognostic_mask(c->cfg.model), "Y"))) return rc;
+    if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
+    (void)hipSetDevice(c->device);
+    if ((rc = materialize(c, Y, ~0u)) || (rc = materialize(c, Ya, ~0u))) return rc;
+    Range r_("lh:boundary_fluxes");
+    return c->cfg.dtype == LH_F64 ? boundary_fluxes_impl<double>(c, Y, Ya, face, f_energy, f_water)
+                                  : boundary_fluxes_impl<float>(c, Y, Ya, face, f_energy, f_water);
 }
 
 int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* out) {

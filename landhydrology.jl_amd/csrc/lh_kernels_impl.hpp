@@ -1210,6 +1210,44 @@ diag_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, co
     }
 }
 
+// ------------------------------------------------------ boundary fluxes
+// boundary_fluxes(X, bc, face, model, cs, t) (boundary_conditions.jl:470-489; the prescribed
+// atmosphere :516-533 arrives as per-column flux values) for ONE face of every column: the pair
+// (f_rhoe_int, f_vartheta_l) the tendency launch puts into its SetValue divergence, from the same
+// device functions, the same closure instantiation (FACTORS, math policy, K without Ksat times Ksat)
+// and therefore the same bits.  A component without a boundary condition (NoBC) gives NaN.
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M>
+__global__ void __launch_bounds__(256)
+boundary_flux_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AUX, const int face, FT* out_e, FT* out_w) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 1];
+    const M mm(stage_math_tables<M>(P.math_tab, s_tab));
+    const int64_t col = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (col >= P.ncols) return;
+    // interior_values (:174-190): the cell next to the face
+    const int64_t o = int64_t(face == FACE_BOTTOM ? 0 : P.nlev - 1) * P.stride + col;
+    ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
+    if (WATER) finish_colc<FT, M>(mm, c);
+    const bool vgf = M::uses_tables && P.vg_fast_all != 0;
+    const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
+    const FT vl = (MODEL == MODEL_HEAT ? AUX.v[0] : IN.v[0])[o];
+    const FT ti = (MODEL == MODEL_HEAT ? AUX.v[1] : IN.v[1])[o];
+    FT T = need_Taux ? AUX.v[3][o] : FT(288), K = FT(0), psi = FT(0), rcs = FT(1);
+    if (HEAT) T = temperature_closure<FT, M>(mm, P, c, vl, ti, IN.v[2][o], rcs);
+    constexpr bool RELK = M::is_production;
+    if (WATER) {
+        water_closures<FT, M, FACTORS, true, false, false, RELK>(mm, P, c, vl, ti, T, K, psi, nullptr, vgf);
+        if (RELK) K = K * c.Ksat; // (as rhs_kernel hands the boundary cell's conductivity over)
+    }
+    FT fe, fw;
+    boundary_fluxes<FT, M, MODEL, FACTORS, false>(mm, P, c, face, col, vl, ti, T, K, psi, fe, fw, nullptr, nullptr, vgf);
+    if (P.bc_kind[face][COMP_ENERGY] == BC_NONE) fe = FT(NAN);
+    if (P.bc_kind[face][COMP_HYDROLOGY] == BC_NONE) fw = FT(NAN);
+    out_e[col] = fe;
+    out_w[col] = fw;
+}
+
 // ---------------------------------------------------------- stable dt
 // min over cells of courant*dz^2/max(K dpsi/dvl, kappa/rho_c_s) (build-defined;
 // the reference steps with a fixed user dt, simulation.jl:34-70).  Positive IEEE
@@ -1703,6 +1741,37 @@ void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>&
 }
 
 template <typename FT>
+void launch_boundary_fluxes(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux, int face, FT* out_e,
+                            FT* out_w, bool factors, bool percol, int math, hipStream_t s) {
+    dim3 g = grid_for(P.ncols, 256), b(256);
+#define LH_BF(MODEL, F, PC, MATH) hipLaunchKernelGGL((boundary_flux_kernel<FT, MODEL, F, PC, MATH>), g, b, 0, s, P, in, aux, face, out_e, out_w)
+#define LH_BF_M(MODEL, MATH)                                \
+    do {                                                    \
+        if (factors) {                                      \
+            if (percol) LH_BF(MODEL, true, true, MATH);     \
+            else LH_BF(MODEL, true, false, MATH);           \
+        } else {                                            \
+            if (percol) LH_BF(MODEL, false, true, MATH);    \
+            else LH_BF(MODEL, false, false, MATH);          \
+        }                                                   \
+    } while (0)
+#define LH_BF_MODEL(MATH)                                              \
+    switch (P.model) {                                                 \
+        case MODEL_RICHARDS: LH_BF_M(MODEL_RICHARDS, MATH); break;     \
+        case MODEL_HEAT: LH_BF_M(MODEL_HEAT, MATH); break;             \
+        default: LH_BF_M(MODEL_COUPLED, MATH); break;                  \
+    }
+    if (math == MATH_LIBM) {
+        LH_BF_MODEL(MathLibm<FT>)
+    } else {
+        LH_BF_MODEL(MathFast<FT>)
+    }
+#undef LH_BF_MODEL
+#undef LH_BF_M
+#undef LH_BF
+}
+
+template <typename FT>
 void launch_stable_dt(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                       FT courant, void* out_ft, bool percol, hipStream_t s) {
     using U = typename Bits<FT>::type;
@@ -1778,6 +1847,8 @@ void launch_convert(FT* dst, const double* src, int64_t n, hipStream_t s) {
                                   const Planes<FT>&, bool, int, hipStream_t);                         \
     template void launch_stable_dt<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&,    \
                                        FT, void*, bool, hipStream_t);                                 \
+    template void launch_boundary_fluxes<FT>(const DevParams<FT>&, const Planes<FT>&, const Planes<FT>&, int, FT*, FT*, \
+                                             bool, bool, int, hipStream_t);                           \
     template void launch_strided_copy<FT>(FT*, int64_t, FT*, int64_t, int64_t, int64_t, int, bool,    \
                                           hipStream_t);                                               \
     template void launch_stream_probe<FT>(int64_t, int64_t, int, int, const Planes<FT>&, int,         \

@@ -45,6 +45,10 @@ void launch_column_stepper(const DevParams<FT>& P, const Planes<FT>& Y, const Pl
 template <typename FT>
 void launch_diag(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                  const Planes<FT>& out, bool percol, int math, hipStream_t s);
+// boundary_fluxes of one face for every column (lh_boundary_fluxes): FT[ncols] each
+template <typename FT>
+void launch_boundary_fluxes(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux, int face, FT* out_e,
+                            FT* out_w, bool factors, bool percol, int math, hipStream_t s);
 template <typename FT>
 void launch_stable_dt(const DevParams<FT>& P, const Planes<FT>& in, const Planes<FT>& aux,
                       FT courant, void* out_ft, bool percol, hipStream_t s);

@@ -260,6 +260,25 @@ function device_rhs!(ens::ColumnEnsemble, dY::DeviceState, Y::DeviceState, Ya, t
     return dY
 end
 
+"""
+    boundary_fluxes(ens, Y, Ya, face, t) -> (fρe_int = ..., fϑ_l = ...)
+
+`boundary_fluxes(X, bc::SoilComponentBC, face, model, cs, t)` (boundary_conditions.jl:470-489) of every
+column for the device state: the two SetValue fluxes of the tendency launch (same device functions),
+`ncolumns` values each; `NaN` where the component has no boundary condition (`nothing` there).
+"""
+function boundary_fluxes(ens::ColumnEnsemble, Y::DeviceState, Ya, face::Symbol, t)
+    face in (:top, :bottom) || throw(ArgumentError("Expected :top or :bottom"))
+    set_bcs!(ens, t)
+    ya = Ya === nothing ? C_NULL : Ya.handle
+    fe = Vector{Float64}(undef, ens.ncolumns)
+    fw = Vector{Float64}(undef, ens.ncolumns)
+    check(ens.ctx, ccall((:lh_boundary_fluxes, lib), Cint,
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Ptr{Float64}, Ptr{Float64}),
+                         ens.ctx, Y.handle, ya, Float64(t), face === :top ? Int32(1) : Int32(0), fe, fw))
+    return (fρe_int = fe, fϑ_l = fw)
+end
+
 # Planes of Ya the DEVICE reads (the prescribed fields of make_update_aux, right_hand_side.jl:54-81):
 # (ϑ_l, θ_i) for a prescribed hydrology; T for a prescribed temperature only when a viscosity
 # factor consumes it (:160).  Mask bits as LH_MASK(var) of include/landhydro.h.

@@ -822,18 +822,43 @@ def compute_turbulent_surface_fluxes(energy, hydrology, model: SoilModel, varthe
 
 
 def boundary_fluxes(X, bc, face, model: SoilModel, cs=None, t=0.0):
-    """boundary_fluxes(X, bc::PrescribedAtmosForcing, face, model, cs, t)
-    (boundary_conditions.jl:516-533) for a host-side X = (ϑ_l, θ_i, T) of the cell next to the
-    face: the named pair (fρe_int, fϑ_l).  Component boundary conditions are evaluated inside the
-    tendency kernel and have no host form here."""
-    if not isinstance(bc, PrescribedAtmosForcing):
-        raise NotImplementedError("component boundary conditions are evaluated on the device by rhs!")
-    if face not in ("top", ":top"):
+    """boundary_fluxes(X, bc, face, model, cs, t) (boundary_conditions.jl:470-489, :516-533): the named
+    pair (fρe_int, fϑ_l) of one face -- the two SetValue fluxes of the tendency -- for every column.
+
+    * `bc` a PrescribedAtmosForcing and `X = (ϑ_l, θ_i, T)` host values of the top cell: the
+      surface fluxes of those states (compute_turbulent_surface_fluxes), as the reference's tests
+      call it.
+    * `bc` a SoilComponentBC (the model's own `boundary_conditions.top` / `.bottom`) and `X` the
+      device state -- `Y`, or `(Y, Ya)` when the model reads prescribed fields: evaluated on the
+      device by the function the tendency kernel uses (lh_boundary_fluxes), [ncolumns] each; a
+      component without a boundary condition gives NaN (`nothing` in the reference)."""
+    tag = face.lstrip(":") if isinstance(face, str) else face
+    if tag not in ("top", "bottom"):
+        raise ValueError("Expected :top or :bottom")                 # boundary_conditions.jl:188
+    if isinstance(bc, PrescribedAtmosForcing) and not isinstance(X, (FieldVector, tuple)) or (
+            isinstance(bc, PrescribedAtmosForcing) and isinstance(X, tuple) and not isinstance(X[0], FieldVector)):
+        if tag != "top":
+            raise RuntimeError("Prescribed atmosphere-driven boundary conditions are only valid at the "
+                               "top of the soil column.")            # :523-528
+        vl, ti, T = X
+        h, w = compute_turbulent_surface_fluxes(model.energy_model, model.hydrology_model, model, vl, ti, T)
+        return {"fρe_int": h, "fϑ_l": w}
+    if isinstance(bc, PrescribedAtmosForcing) and tag != "top":
         raise RuntimeError("Prescribed atmosphere-driven boundary conditions are only valid at the "
-                           "top of the soil column.")            # :523-528
-    vl, ti, T = X
-    h, w = compute_turbulent_surface_fluxes(model.energy_model, model.hydrology_model, model, vl, ti, T)
-    return {"fρe_int": h, "fϑ_l": w}
+                           "top of the soil column.")
+    if bc is not getattr(model.boundary_conditions, tag):
+        raise ValueError("boundary_fluxes on the device evaluates the model's own boundary condition of that face: "
+                         f"pass model.boundary_conditions.{tag}")
+    Y, Ya = X if isinstance(X, tuple) else (X, None)
+    be = model._backend()
+    be.set_bcs(model, t)
+    d = model.domain
+    fe, fw = np.empty(d.ncolumns), np.empty(d.ncolumns)
+    ya = Ya.handle if isinstance(Ya, FieldVector) else None
+    F.check(F.lib().lh_boundary_fluxes(be.ctx, Y.handle, ya, float(t), F.LH_FACE_TOP if tag == "top" else F.LH_FACE_BOTTOM,
+                                       fe.ctypes.data_as(C.POINTER(C.c_double)), fw.ctypes.data_as(C.POINTER(C.c_double))),
+            be.ctx)
+    return {"fρe_int": fe.astype(d.FT), "fϑ_l": fw.astype(d.FT)}
 
 
 def stable_dt(model: SoilModel, Y: "FieldVector", Ya=None, courant: float = 0.5) -> float:

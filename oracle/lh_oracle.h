@@ -204,6 +204,16 @@ int lho_diagnostics_f32(const lho_model*, const lho_percol*, int64_t ncols, cons
                         float* psi, float* T, float* kappa, int64_t lev_stride,
                         int64_t col_stride);
 
+/* boundary_fluxes(X, bc, face, model, cs, t) (boundary_conditions.jl:470-489, :516-533) per column:
+ * the SetValue flux pair (f_rhoe_int, f_vartheta_l) of one face, [ncols] each; NaN for a component
+ * without a boundary condition. */
+int lho_boundary_fluxes_f64(const lho_model*, const lho_percol*, int64_t ncols, const double* vl,
+                            const double* ti, const double* rhoe, const double* T_aux,
+                            int64_t lev_stride, int64_t col_stride, int face, double* f_e, double* f_w);
+int lho_boundary_fluxes_f32(const lho_model*, const lho_percol*, int64_t ncols, const float* vl,
+                            const float* ti, const float* rhoe, const float* T_aux,
+                            int64_t lev_stride, int64_t col_stride, int face, float* f_e, float* f_w);
+
 /* ---- SSPRK33, fixed dt (OrdinaryDiffEq SSPRK33 as driven by
  * src/Simulations/simulation.jl:58-70; Shu-Osher form, stage times
  * t, t+dt, t+dt/2).  State arrays are advanced in place.  bc_stage_values is

@@ -133,6 +133,7 @@ def _declare(L):
         sig("lho_ssprk33", C.c_int, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double, C.c_double,
                                      i64, _DP, C.c_int])
         sig("lho_stable_dt", C.c_double, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_double])
+        sig("lho_boundary_fluxes", C.c_int, [mp, pcp, i64, P, P, P, P, i64, i64, C.c_int, P, P])
         sig("lho_turbulent_surface_fluxes", C.c_int, [mp, ft, ft, ft, P, P])
     L.lho_openmp_max_threads.restype = C.c_int
 
@@ -287,6 +288,25 @@ def diagnostics(om, vl=None, ti=None, rhoe=None, T_aux=None):
     if rc:
         raise ValueError(f"oracle diagnostics failed (code {rc})")
     return dict(K=K, psi=psi, T=T, kappa=kap)
+
+
+def boundary_fluxes(om, face, vl, ti, rhoe=None, T_aux=None):
+    """boundary_fluxes(X, bc, face, model, cs, t) per column: (f_rhoe_int[ncols], f_vartheta_l[ncols])
+    of one face (NaN where the component has no boundary condition).  HEAT: vl, ti are the
+    prescribed (aux) fields."""
+    dtype = vl.dtype
+    ft = _ft(dtype)
+    ls, cs = _strides(vl)
+    fe, fw = np.empty(vl.shape[0], dtype), np.empty(vl.shape[0], dtype)
+    m = c_model(om)
+    pc, keep = c_percol(om)
+    rc = fn("lho_boundary_fluxes", dtype)(C.byref(m), C.byref(pc) if pc is not None else None, vl.shape[0],
+                                          _ptr(vl, ft), _ptr(ti, ft), _ptr(rhoe, ft), _ptr(T_aux, ft), ls, cs,
+                                          int(face), _ptr(fe, ft), _ptr(fw, ft))
+    del keep
+    if rc:
+        raise ValueError(f"oracle boundary_fluxes failed (code {rc})")
+    return fe, fw
 
 
 def ssprk33(om, dt, nsteps, vl=None, ti=None, rhoe=None, T_aux=None, t0=0.0,
