@@ -3,10 +3,14 @@ CPU oracle on the same seeded inputs (tests/parity_cases.py).
 
 Tolerance: `tendency_tolerance` propagates Cw*eps(FT) through the cancelling
 sub-expressions of the closures and the flux differences (see parity_cases.py).
-Cw = 4 (Float64, and Float32 with the libm policy): the two implementations may
-differ by a few units of rounding per operation, nothing more.  Cw = 16 for the
+Cw = 2 (Float64; Float32 with the libm policy: 4): the two implementations may
+differ by a unit or two of rounding per operation, nothing more.  Cw = 4 for the
 Float32 production policy, whose pow is exp2(y log2 x) on the hardware
 v_log_f32 / v_exp_f32 units (about 1 ulp each, six of them in the K chain).
+(Round 3: halved / quartered -- the fixed cases use at most 0.14 of the model at
+Cw = 4 / 0.05 at 16, profiles/round3_plain_statistic.txt; the randomised test keeps
+4 / 16.)  Next to the model a plain statistic is asserted: the share of cells within
+1e-13 (Float64) / 1e-5 (Float32) of the field's largest tendency.
 d(theta_i) must be exactly 0.
 """
 import numpy as np
@@ -16,11 +20,11 @@ import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
 
-CW = 4.0
+CW = 2.0
 
 
 def cw(case, math="fast"):
-    return 16.0 if (case.dtype == np.float32 and math == "fast") else CW
+    return CW if case.dtype == np.float64 else 4.0
 
 CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c4_richards_f64_128",
          "c3_coupled_f32", "c3_coupled_f64", "c5_percol_f64", "heat_dirichlet_f64",
@@ -37,7 +41,7 @@ def test_rhs_matches_oracle(name, math):
     mode = F.LH_MATH_FAST if math == "fast" else F.LH_MATH_LIBM
     got = pc.run_gpu_rhs(case, mode)
     want = pc.run_oracle_rhs(case)
-    pc.assert_tendencies_close(case, got, want, cw(case, math), label=f"[{math}]")
+    pc.assert_tendencies_close(case, got, want, cw(case, math), label=f"[{math}]", plain=True)
 
 
 @pytest.mark.parametrize("name", ["c2_richards_f64", "c3_coupled_f32", "mixed_factors_f64",

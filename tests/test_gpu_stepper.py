@@ -95,7 +95,9 @@ def test_theta_zt_matches_oracle_f32(name, nsteps):
     dt = stable_dt(case)
     got = gpu_steps(case, dt, nsteps)
     want = cpu_steps(case, dt, nsteps)
-    assert_state_close(case, got, want, 2e-5)
+    # measured on MI355X: 2e-7 ... 1.0e-6 of the field scale (profiles/round2_f32_bound.json,
+    # round3_f32_drift.json); the bound leaves a factor 3, so a 10x regression fails
+    assert_state_close(case, got, want, 3e-6)
 
 
 def test_time_dependent_dirichlet_stage_values():
@@ -503,6 +505,51 @@ def test_f32_theta_zt_is_as_close_to_f64_as_the_reference_arithmetic_is(name, ns
     if os.path.isdir(out):
         with open(os.path.join(out, "f32_bound.json"), "w") as fh:
             json.dump(F32_BOUND_RESULTS, fh, indent=1)
+
+
+def test_f32_drift_over_2000_steps_stays_with_the_reference_arithmetic():
+    """The Float32 statement of the previous test over a LONG horizon: 2000 SSPRK33 steps of the
+    coupled configuration C3 (6000 evaluations of f), checked every 200 steps --
+        max|H32 - O64| <= 1.5 max|O32 - O64|      per prognostic field at every checkpoint,
+    i.e. the HIP Float32 path drifts from the Float64 trajectory no faster than the reference's own
+    Float32 arithmetic does.  Both growth curves are recorded (gpurun_out/f32_drift.json ->
+    profiles/round3_f32_drift.json)."""
+    import json
+    import os
+    case32 = pc.make_case("c3_coupled_f32", ncols=192)
+    case64 = _as_f64_problem(case32)
+    dt = float(np.float32(stable_dt(case32)))
+    chunk, nchunks = 200, 10
+    curves = {"dt": dt, "steps": [], "fields": {}}
+    with pc.GpuModel(case32) as g:
+        F = g.F
+        Y, Ya = g.prognostic_and_aux()
+        o32 = {k: getattr(case32, k).copy() for k in ("vl", "ti", "rhoe")}
+        o64 = {k: getattr(case64, k).copy() for k in ("vl", "ti", "rhoe")}
+        for c in range(nchunks):
+            F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, dt, chunk, None), g.ctx)
+            O.ssprk33(case32.om, dt, chunk, vl=o32["vl"], ti=o32["ti"], rhoe=o32["rhoe"], nthreads=8)
+            O.ssprk33(case64.om, dt, chunk, vl=o64["vl"], ti=o64["ti"], rhoe=o64["rhoe"], nthreads=8)
+            H = {"vl": g.download(Y, F.LH_VAR_VARTHETA_L), "rhoe": g.download(Y, F.LH_VAR_RHOE_INT)}
+            curves["steps"].append((c + 1) * chunk)
+            for k in ("vl", "rhoe"):
+                w = o64[k]
+                scale = np.max(np.abs(w))
+                dH = float(np.max(np.abs(H[k].astype(np.float64) - w)) / scale)
+                dO = float(np.max(np.abs(o32[k].astype(np.float64) - w)) / scale)
+                curves["fields"].setdefault(k, {"H32_vs_O64": [], "O32_vs_O64": []})
+                curves["fields"][k]["H32_vs_O64"].append(dH)
+                curves["fields"][k]["O32_vs_O64"].append(dO)
+                assert dO > 0 and dH <= 1.5 * dO, (k, (c + 1) * chunk, dH, dO)
+        assert g.status() == 0
+        assert np.array_equal(g.download(Y, F.LH_VAR_THETA_I), case32.ti)
+    # the state moved far more than the distances compared
+    assert np.max(np.abs(o64["vl"] - case64.vl)) > 1e3 * curves["fields"]["vl"]["O32_vs_O64"][-1] * np.max(np.abs(o64["vl"]))
+    print("\nF32_DRIFT " + json.dumps(curves))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "f32_drift.json"), "w") as fh:
+            json.dump(curves, fh, indent=1)
 
 
 # --------------------------------- property pins for the BC branches no reference vector covers
