@@ -87,6 +87,10 @@ WORKLOADS = {
     # 50 levels: one more plane read)
     "f3c32": ("mixed_smooth_f32", 24.0, "f32"),
     "f3c64": ("mixed_smooth_f64", 48.0, "f64"),
+    # ... the same ensembles with their columns ordered ice-free first (workloads.ice_sorted_order): waves
+    # are then all-ice-free or all-icy instead of mixed
+    "f3c32s": ("mixed_smooth_f32_icesorted", 24.0, "f32"),
+    "f3c64s": ("mixed_smooth_f64_icesorted", 48.0, "f64"),
     "f3v64": ("richards_viscosity_f64", 40.0, "f64"),
     # ... and with the prescribed temperature level-uniform, as the reference's T_profile(z, t) is:
     # nlev numbers (lh_upload_profile), read from LDS -- no T plane is streamed

@@ -144,7 +144,14 @@ def lib() -> C.CDLL:
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            f = getattr(L, name)
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                # tools/ab_libs.py times OLDER builds of the library next to the product one: those may
+                # lack the newest entry points (the product library never does: tests/test_abi_cpu.py)
+                if os.environ.get("LH_ALLOW_MISSING_SYMBOLS") == "1":
+                    continue
+                raise
             f.restype, f.argtypes = res, args
         _lib = L
     return _lib

@@ -206,6 +206,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     P.dz = (FT(c->cfg.zmax) - FT(c->cfg.zmin)) / FT(c->cfg.nlev);
     P.inv_dz = FT(1) / P.dz;
     P.half_inv_dz = FT(0.5) * P.inv_dz;
+    P.cg2 = P.half_inv_dz * P.inv_dz;
     P.half_dz = P.dz / FT(2);
     P.zc = static_cast<const FT*>(c->d_zc);
     P.vg_n = FT(h.vg.n);
@@ -256,6 +257,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
     u.inv_m = FT(1) / u.m;
     u.alpha_pnn = host_pow<FT>(P.vg_alpha, -u.n);
     u.Ksat = P.vg_Ksat;
+    u.cgw = P.cg2 * u.Ksat;
     u.inv_por = FT(1) / (u.nu - u.theta_r);
     u.inv_S_s = FT(1) / u.S_s;
     u.inv_nu = FT(1) / u.nu;
@@ -270,7 +272,7 @@ DevParams<FT> make_params(const lh_ctx* c) {
         u.e_inv_n = u.inv_n;
         u.e_log2_alpha = sc * u.log2_alpha;
     }
-    if (!(u.nu > u.theta_r)) u.Ksat = u.inv_S_s = u.log2_alpha = u.e_log2_alpha = u.alpha_pnn = FT(NAN);
+    if (!(u.nu > u.theta_r)) u.Ksat = u.cgw = u.inv_S_s = u.log2_alpha = u.e_log2_alpha = u.alpha_pnn = FT(NAN);
     {
         FT rho_b = (FT(1) - u.nu) * P.rho_p;
         FT num = (P.kappa_dry_parameter * P.kappa_solid - P.k_air) * rho_b + P.k_air * P.rho_p;

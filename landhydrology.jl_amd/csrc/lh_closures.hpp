@@ -40,6 +40,7 @@ template <typename FT>
 __host__ __device__ inline void poison_invalid(ColC<FT>& c) {
     if (!(c.nu > c.theta_r)) {
         c.Ksat = FT(NAN);
+        c.cgw = FT(NAN);
         c.inv_S_s = FT(NAN);
         c.log2_alpha = FT(NAN);
         c.e_log2_alpha = FT(NAN);
@@ -74,6 +75,7 @@ __device__ __forceinline__ ColC<FT> make_colc(const DevParams<FT>& P, int64_t co
     c.inv_S_s = FT(1) / c.S_s;
     c.inv_nu = FT(1) / c.nu;
     c.log2_alpha = MathLibm<FT>::log2(alpha);
+    c.cgw = P.cg2 * c.Ksat;
     set_fast_vg(c, alpha);
     set_scaled_exponents(c, FT(M::EXP2_SCALE));
     poison_invalid(c);
@@ -180,7 +182,11 @@ __device__ __forceinline__ bool wave_all(bool pred) {
 
 // RELK: K is returned WITHOUT the factor Ksat (relative conductivity times the conductivity factors);
 // the column kernels fold Ksat into the per-column flux constant instead of multiplying every cell.
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false>
+// BRANCHY: the saturated cells are a divergent branch around the power chain (few live registers:
+// the Float64 coupled kernels are register-bound) instead of every lane running the chain and a
+// wave-level repair (fewest instructions: the Richards kernels are issue-bound).  Same values.
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false,
+          bool BRANCHY = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                    FT& psi, float* dpsi = nullptr, bool vgfast = false) {
@@ -235,29 +241,57 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         }
         return mm.exp2_scaled(x * y);
     };
-    // EVERY lane runs the unsaturated chain (saturated cells are rare: their lanes compute values
-    // nobody uses -- table offsets are masked, nothing traps) and a wave with a saturated cell
-    // repairs those lanes in a real branch below: no divergent-branch bookkeeping per cell.
-    FT L = mm.log2(S);                             // log2 S
-    const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
-    const FT w = FT(1) - ex2(a);
-    const FT Lw = mm.log2(w);
-    const FT inner = FT(1) - ex2_prod(Lw, c.e_m);
-    FT Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner); // K without the conductivity factors (FACTORS: without sqrt(S) too)
-    if (!RELK) Kb = Kb * c.Ksat;
-    if (WANT_PSI && shared) {
-        psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
-        if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
-    }
-    if (__builtin_amdgcn_ballot_w64(!unsat) != 0ull) { // (a NaN saturation lands here too, as in the reference's `S < 1 ? ... : ...`)
-        FT vin = vl; // (opaque: the compiler must not turn this block into per-cell selects)
-        asm volatile("" : "+v"(vin));
-        L = unsat ? L : FT(0);   // K_r = 1, and sqrt(S) = 2^0 in the factor product below
-        Kb = unsat ? Kb : (RELK ? FT(1) : c.Ksat);
+    FT L, Kb;
+    if constexpr (BRANCHY) {
+        L = FT(0); // log2 S of an unsaturated cell (0 otherwise: K_r = 1, and sqrt(S) = 2^0 below)
+        if (unsat) {
+            L = mm.log2(S);
+            const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
+            const FT w = FT(1) - ex2(a);
+            const FT Lw = mm.log2(w);
+            const FT inner = FT(1) - ex2_prod(Lw, c.e_m);
+            Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner);
+            if (!RELK) Kb = Kb * c.Ksat;
+            if (WANT_PSI && shared) {
+                psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
+                if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+            }
+        } else {
+            // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
+            // compiler evaluates it for every cell and selects)
+            Kb = RELK ? FT(1) : c.Ksat; // K_r = 1
+            if (WANT_PSI && shared) {
+                FT vin = vl; // (opaque INPUT: nothing of the saturated evaluation can move above the branch)
+                asm volatile("" : "+v"(vin));
+                psi = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
+                if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
+            }
+        }
+    } else {
+        // EVERY lane runs the unsaturated chain (saturated cells are rare: their lanes compute values
+        // nobody uses -- table offsets are masked, nothing traps) and a wave with a saturated cell
+        // repairs those lanes in a real branch below: no divergent-branch bookkeeping per cell.
+        L = mm.log2(S);                                // log2 S
+        const FT a = L * c.e_inv_m;                    // scale * log2 S^(1/m)
+        const FT w = FT(1) - ex2(a);
+        const FT Lw = mm.log2(w);
+        const FT inner = FT(1) - ex2_prod(Lw, c.e_m);
+        Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner); // K without the conductivity factors (FACTORS: without sqrt(S) too)
+        if (!RELK) Kb = Kb * c.Ksat;
         if (WANT_PSI && shared) {
-            const FT ps = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
-            psi = unsat ? psi : ps;
-            if (WANT_DPSI) *dpsi = unsat ? *dpsi : float(c.n * c.m * c.inv_S_s);
+            psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
+            if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+        }
+        if (__builtin_amdgcn_ballot_w64(!unsat) != 0ull) { // (a NaN saturation lands here too, as in the reference's `S < 1 ? ... : ...`)
+            FT vin = vl; // (opaque: the compiler must not turn this block into per-cell selects)
+            asm volatile("" : "+v"(vin));
+            L = unsat ? L : FT(0);   // K_r = 1, and sqrt(S) = 2^0 in the factor product below
+            Kb = unsat ? Kb : (RELK ? FT(1) : c.Ksat);
+            if (WANT_PSI && shared) {
+                const FT ps = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
+                psi = unsat ? psi : ps;
+                if (WANT_DPSI) *dpsi = unsat ? *dpsi : float(c.n * c.m * c.inv_S_s);
+            }
         }
     }
     if (!NOICE && WANT_PSI && !shared) { // ice somewhere in the wave: psi from every lane's own saturation
@@ -295,13 +329,14 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
-template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false>
+template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false,
+          bool BRANCHY = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                FT& psi, float* dpsi = nullptr, bool vgfast = false) {
     static_assert(!RELK || M::is_production, "the relative-conductivity form exists for the production math only");
     if (M::is_production) {
-        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE, RELK>(mm, P, c, vl, ti, T, K, psi, dpsi, vgfast);
+        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE, RELK, BRANCHY>(mm, P, c, vl, ti, T, K, psi, dpsi, vgfast);
     } else {
         water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
         if (WANT_DPSI) { // as the oracle writes it

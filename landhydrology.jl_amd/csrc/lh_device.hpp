@@ -21,6 +21,7 @@ struct ColC {
     FT n, inv_n, m, inv_m;          // m = 1 - 1/n (SoilWaterParameterizations.jl:167)
     FT alpha_pnn;                   // alpha^(-n)
     FT Ksat;
+    FT cgw;                         // cg2 * Ksat: the water flux constant of the column kernels (K is carried without Ksat)
     FT k_dry;                       // SoilHeatParameterizations.jl:280-294
     FT inv_por, inv_S_s, inv_nu;    // 1/(nu - theta_r), 1/S_s, 1/nu
     FT log2_alpha;                  // log2(alpha), for the log-domain psi
@@ -48,6 +49,8 @@ struct DevParams {
     FT dz;        // (zmax - zmin) / nlev            (domain.jl:64)
     FT inv_dz;    // 1 / dz
     FT half_inv_dz; // (1/2) / dz: the arithmetic-mean factor of InterpolateC2F folded into GradientC2F (exact)
+    FT cg2;       // (1/2) / dz^2 = half_inv_dz * inv_dz: the factor of a centre difference that makes a flux a TENDENCY
+                  // (host-computed: a product of two kernel arguments would live in VGPRs -- there is no scalar f64 multiply)
     FT half_dz;   // boundary centre-to-face distance (boundary_conditions.jl:196-208)
     const FT* zc; // device array [nlev], coordinates(cs)
 

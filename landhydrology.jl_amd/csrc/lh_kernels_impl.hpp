@@ -72,8 +72,13 @@ constexpr int rhs_waves_per_simd() {
 #ifndef LH_F64_FACTORS_STAGE_WAVES4
 #define LH_F64_FACTORS_STAGE_WAVES4 0
 #endif
+#ifndef LH_F64_FACTORS_TEND_WAVES
+#define LH_F64_FACTORS_TEND_WAVES 3
+#endif
+    // (round 3: the tendency kernel now needs 154 VGPRs unconstrained; bounded to 127 it spills 84 B per
+    // lane to scratch and runs 0.75 instead of 0.53 ms -- 3 waves/SIMD, no scratch)
     if (M::is_production && FACTORS && sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && !PERCOL &&
-        (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return 4;
+        (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return LH_F64_FACTORS_TEND_WAVES;
     if (!M::is_production || FACTORS) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? LH_PERCOL_DT_WAVES : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
     if (PERCOL) return 1;
@@ -397,12 +402,12 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // F = -(K_lo + K_hi) (dh (1/2)/dz), -(F_hi - F_lo)/dz, a rounding-level regrouping.  Boundary
     // fluxes (physical units, boundary_fluxes) are scaled by 1/dz once per column.
     constexpr bool RELK = M::is_production;
-    const FT cgT = P.half_inv_dz * P.inv_dz;
+    const FT cgT = P.cg2;
     FT cgw[CPL], Ksc[CPL]; // water flux constant; the factor that makes a closure K a true conductivity
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         Ksc[j] = RELK ? c[j].Ksat : FT(1);
-        cgw[j] = cgT * Ksc[j];
+        cgw[j] = RELK ? c[j].cgw : cgT;
     }
 
     FT vl[CPL], ti[CPL], re[CPL], Ta[CPL];         // current cell inputs
@@ -557,8 +562,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 if (WANT_DT) ircs[j] = float(mm.rcp(rcs[j])); // (the reciprocal temperature_closure formed)
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE, RELK>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
-                                                                           psi[j], &dpsi[j], vgf);
+                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE, RELK, HEAT>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
+                                                                                 psi[j], &dpsi[j], vgf);
                 h[j] = psi[j] + z;
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
@@ -764,9 +769,9 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     constexpr bool vgf = VGF && M::uses_tables; // (as rhs_kernel)
     // fluxes in tendency units, K without Ksat: rhs_kernel's constants and expressions, to the letter
     constexpr bool RELK = M::is_production;
-    const FT cgT = P.half_inv_dz * P.inv_dz;
+    const FT cgT = P.cg2;
     const FT Ksc = RELK ? c.Ksat : FT(1);
-    const FT cgw = cgT * Ksc;
+    const FT cgw = RELK ? c.cgw : cgT;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     // Planes are column-fastest, threads here are level-fastest: go through LDS tiles so that
     // global memory sees the cpb adjacent columns of a level as one contiguous piece.  All
@@ -816,7 +821,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 kap = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl, ti);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, false, NOICE, RELK>(mm, P, c, u_vl, ti, T, K, psi, nullptr, vgf);
+                water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT>(mm, P, c, u_vl, ti, T, K, psi, nullptr, vgf);
                 h = psi + z;
                 if (HEAT) E = (P.rhocp_l * (T - P.T_ref)) * K; // rho_e_int_l * K (:364)
             }
@@ -977,9 +982,9 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
     if (WATER && !NOICE) finish_colc<FT, M>(mm, c);
     constexpr bool vgf = VGF && M::uses_tables;
     constexpr bool RELK = M::is_production; // fluxes in tendency units, K without Ksat: as rhs_kernel, to the letter
-    const FT cgT = P.half_inv_dz * P.inv_dz;
+    const FT cgT = P.cg2;
     const FT Ksc = RELK ? c.Ksat : FT(1);
-    const FT cgw = cgT * Ksc;
+    const FT cgw = RELK ? c.cgw : cgT;
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && FACTORS && P.viscosity_kind;
     // planes are column-fastest, lanes here level-fastest: through LDS tiles [cpb][n] (column_stepper_kernel)
     FT* tiles = reinterpret_cast<FT*>(s_dyn);
@@ -1044,7 +1049,7 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
                     kap[q] = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl[q], ti[q]);
                 }
                 if (WATER) {
-                    water_closures<FT, M, FACTORS, true, false, NOICE, RELK>(mm, P, c, u_vl[q], ti[q], T[q], K[q], psi[q], nullptr, vgf);
+                    water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT>(mm, P, c, u_vl[q], ti[q], T[q], K[q], psi[q], nullptr, vgf);
                     h[q] = psi[q] + z[q];
                     if (HEAT) E[q] = (P.rhocp_l * (T[q] - P.T_ref)) * K[q]; // rho_e_int_l * K (:364)
                 }

@@ -119,6 +119,9 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0, _nlev
     f64, f32 = np.float64, np.float32
     # "<family>_nNNN": the family's case with NNN levels (tall and ragged columns: 65..128 levels are
     # one wavefront with two cells per lane in the persistent stepper, more than 128 one thread per cell)
+    if name.endswith("_icesorted"):   # the family's case with ice-free columns first (ice_sorted_order)
+        base = make_case(name[:-len("_icesorted")], ncols, col_offset, _nlev=_nlev)
+        return reorder_columns(base, ice_sorted_order(base.ti))
     nlev_override = None
     mm_ = re.match(r"^(.*)_n(\d+)$", name)
     if mm_:
@@ -275,6 +278,30 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0, _nlev
 
 
 # ------------------------------------------------------------ oracle runner
+
+def ice_sorted_order(theta_i: np.ndarray) -> np.ndarray:
+    """order[k] = the column that should sit at position k so that ice-free columns come first and
+    columns with any ice last (a stable partition).  theta_i never changes (its tendency is identically
+    zero: right_hand_side.jl:182, :359), so the pattern is static: with the columns laid out in this
+    order a wavefront (64 consecutive columns) is either ice-free -- K and psi then share one power
+    chain, water_closures_log -- or icy, and at most one wave per ensemble is mixed.  Columns are
+    independent: any order gives the same per-column results bit for bit."""
+    icy = np.any(np.asarray(theta_i) != 0, axis=1)
+    return np.argsort(icy, kind="stable")
+
+
+def reorder_columns(case: Case, order: np.ndarray) -> Case:
+    """The same ensemble with its columns in another order (every per-column array permuted)."""
+    import dataclasses
+    take = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a)[order])
+    om = case.om
+    om2 = dataclasses.replace(om, percol={k: take(v) for k, v in om.percol.items()},
+                              percol_bc={k: take(v) for k, v in om.percol_bc.items()})
+    if getattr(om, "percol_atmos", None):
+        om2 = dataclasses.replace(om2, percol_atmos={k: take(v) for k, v in om.percol_atmos.items()})
+    return dataclasses.replace(case, name=case.name + "_sorted", om=om2, vl=take(case.vl), ti=take(case.ti),
+                               rhoe=take(case.rhoe), T_aux=take(case.T_aux))
+
 
 class GpuModel:
     """A context on the HIP library configured from an OracleModel description,

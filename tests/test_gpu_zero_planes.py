@@ -200,3 +200,35 @@ def test_a_kept_device_pointer_stays_trusted_by_nobody():
         g.rhs(Y, Ya, dY)
         pc.assert_tendencies_close(full, g.tendencies(dY), want)
         assert g.status() == 0
+
+
+@pytest.mark.parametrize("name", ["mixed_smooth_f64", "mixed_smooth_f32", "mixed_factors_f64"])
+def test_column_order_does_not_change_a_column(name):
+    """theta_i is static, so callers may order the columns ice-free first (workloads.ice_sorted_order):
+    waves are then all-ice-free or all-icy.  Columns are independent and a lane's result does not
+    depend on what shares its wave: the reordered ensemble gives every column the same bits --
+    tendency, step bound and stepped state."""
+    import torch
+    W = pc._w
+    case = pc.make_case(name)
+    order = W.ice_sorted_order(case.ti)
+    assert 0 < np.count_nonzero(np.any(case.ti != 0, axis=1)) < case.ncols      # a mixed ensemble
+    sorted_case = W.reorder_columns(case, order)
+    out = []
+    for c in (case, sorted_case):
+        with pc.GpuModel(c) as g:
+            F = g.F
+            Y, Ya = g.prognostic_and_aux()
+            dY = g.state(0)
+            tdt = torch.zeros(1, device="cuda", dtype=torch.float64 if c.dtype == np.float64 else torch.float32)
+            F.check(g.L.lh_rhs_stable_dt(g.ctx, 0.0, Y, Ya, dY, 0.4, tdt.data_ptr()), g.ctx)
+            res = g.tendencies(dY)
+            F.check(g.L.lh_synchronize(g.ctx), g.ctx)
+            res["dt"] = np.array([tdt.item()])
+            F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, 0.1 * float(tdt.item()), 4, None), g.ctx)
+            res["Y_vl"], res["Y_re"] = g.download(Y, F.LH_VAR_VARTHETA_L), g.download(Y, F.LH_VAR_RHOE_INT)
+            out.append(res)
+    a, b = out
+    for k in a:
+        want = a[k] if k == "dt" else a[k][order]
+        assert np.array_equal(want, b[k], equal_nan=True), (name, k)
