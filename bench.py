@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-known-zero", action="store_true",
                     help="LH_TUNE zero=0: read theta_i and clear the d theta_i plane at every launch "
                          "(the traffic of SURVEY 8(d)'s byte contract)")
+    ap.add_argument("--no-contract-regime", action="store_true",
+                    help="skip the extra block that times the same launch with the contract traffic (zero=0) after "
+                         "the headline loop (profiling runs: one kernel instantiation per run)")
     ap.add_argument("--no-step-events", action="store_true",
                     help="no HIP events between the timed steps (kernel statistics then come from a "
                          "separate back-to-back block)")
@@ -334,6 +337,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cells = (hi - lo) * nlev
+    esize = np.dtype(case.dtype).itemsize
+    bytes_per_cell = WORKLOADS[a.workload][1]                       # SURVEY 8(d) contract
+    percol_extra = bytes_per_cell - round(bytes_per_cell / esize) * esize   # C5's per-column block
+    moved_per_cell = (nr + nw) * esize + percol_extra
+    bytes_moved = cells * moved_per_cell
+
+    # Ancillary measurements FIRST (order: stream probe, contract-traffic regime, then the W warm-up
+    # steps and the K timed steps): they need the same resident state, and the ~90 launches they issue
+    # bring the device to its sustained clock before the headline loop (a box starts at idle clocks:
+    # the first tens of launches of a short run are 10-20 % slower, see per_step_ms).
+
+    # the ceiling of this access pattern on these very planes: the library's no-arithmetic probe
+    # (reads up to nr planes of Y, writes nw planes of dY; it reports its own plane counts)
+    probe = None
+    try:
+        F.check(L.lh_synchronize(ctx), ctx)
+        y_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]      # theta_i last
+        d_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]
+        rp, wp = y_planes[:nr], d_planes[:nw]
+        pm, wm = sum(1 << v for v in rp), sum(1 << v for v in wp)
+        pms = C.c_float()
+        F.check(L.lh_stream_probe(ctx, Y, pm, dY, wm, 40, C.byref(pms)), ctx)
+        probe = {"gbs": cells * esize * (len(rp) + len(wp)) / (pms.value * 1e-3) / 1e9, "ms": pms.value,
+                 "planes_read": len(rp), "planes_written": len(wp)}
+    except Exception as e:      # noqa: BLE001
+        probe = {"error": repr(e)}
+
+    # The SURVEY 8(d) byte contract as traffic: the same launch with the known-zero planes switched
+    # off (theta_i read, d theta_i = 0 stored: LH_TUNE zero=0), timed in THIS process -- both byte
+    # regimes from one run, one box, one clock.
+    contract = None
+    if not a.no_known_zero and not a.no_contract_regime:
+        try:
+            F.check(L.lh_set_tuning(ctx, b"zero=0"), ctx)
+            for _ in range(5):
+                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+            nk = 60     # (a fixed block, whatever --steps: a measurement of its own)
+            F.check(L.lh_timer_start(ctx), ctx)
+            for _ in range(nk):
+                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
+            cms = C.c_float()
+            F.check(L.lh_timer_stop(ctx, C.byref(cms)), ctx)
+            c_ms = cms.value / nk
+            c_bytes = cells * bytes_per_cell
+            contract = {"kernel_ms": c_ms, "launches_timed": nk, "bytes_per_launch": c_bytes,
+                        "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "frac": c_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "is": "lh_rhs with LH_TUNE zero=0 (every prognostic plane read, every tendency plane "
+                              "written: the bytes of SURVEY 8(d)'s contract really moved), HIP events around a "
+                              "back-to-back block in this same process; the memset of the d theta_i plane is part of it"}
+        except Exception as e:      # noqa: BLE001
+            contract = {"error": repr(e)}
+        finally:
+            F.check(L.lh_set_tuning(ctx, b""), ctx)
+
     for i in range(a.warmup):
         rhs_step(i)
     barrier()
@@ -381,58 +439,9 @@ def main():
         kern_ms, kern_med, kern_min, fused_ms = ms.value / kern_n, None, None, None
         kern_src = "HIP events around a separate back-to-back block of lh_rhs launches (after the timed loop)"
 
-    cells = (hi - lo) * nlev
-    esize = np.dtype(case.dtype).itemsize
-    bytes_per_cell = WORKLOADS[a.workload][1]                       # SURVEY 8(d) contract
-    percol_extra = bytes_per_cell - round(bytes_per_cell / esize) * esize   # C5's per-column block
-    moved_per_cell = (nr + nw) * esize + percol_extra
-    bytes_moved = cells * moved_per_cell
     ms_per_step = wall / a.steps * 1e3
     achieved = bytes_moved / (ms_per_step * 1e-3) / 1e9
     kernel_gbs = bytes_moved / (kern_ms * 1e-3) / 1e9
-
-    # the ceiling of this access pattern on these very planes: the library's no-arithmetic probe
-    # (reads up to nr planes of Y, writes nw planes of dY; it reports its own plane counts)
-    probe = None
-    try:
-        F.check(L.lh_synchronize(ctx), ctx)
-        y_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]      # theta_i last
-        d_planes = {0: [0, 1], 1: [2], 2: [0, 2, 1]}[case.om.model]
-        rp, wp = y_planes[:nr], d_planes[:nw]
-        pm, wm = sum(1 << v for v in rp), sum(1 << v for v in wp)
-        pms = C.c_float()
-        F.check(L.lh_stream_probe(ctx, Y, pm, dY, wm, 20, C.byref(pms)), ctx)
-        probe = {"gbs": cells * esize * (len(rp) + len(wp)) / (pms.value * 1e-3) / 1e9, "ms": pms.value,
-                 "planes_read": len(rp), "planes_written": len(wp)}
-    except Exception as e:      # noqa: BLE001
-        probe = {"error": repr(e)}
-
-    # The SURVEY 8(d) byte contract as traffic: the same launch with the known-zero planes switched
-    # off (theta_i read, d theta_i = 0 stored: LH_TUNE zero=0), timed in THIS process right after
-    # the headline loop -- both byte regimes from one run, one box, one clock.
-    contract = None
-    if not a.no_known_zero:
-        try:
-            F.check(L.lh_set_tuning(ctx, b"zero=0"), ctx)
-            for _ in range(5):
-                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
-            nk = max(10, min(a.steps, 60))
-            F.check(L.lh_timer_start(ctx), ctx)
-            for _ in range(nk):
-                F.check(L.lh_rhs(ctx, 0.0, Y, Ya, dY), ctx)
-            cms = C.c_float()
-            F.check(L.lh_timer_stop(ctx, C.byref(cms)), ctx)
-            c_ms = cms.value / nk
-            c_bytes = cells * bytes_per_cell
-            contract = {"kernel_ms": c_ms, "launches_timed": nk, "bytes_per_launch": c_bytes,
-                        "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "frac": c_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "is": "lh_rhs with LH_TUNE zero=0 (every prognostic plane read, every tendency plane "
-                              "written: the bytes of SURVEY 8(d)'s contract really moved), HIP events around a "
-                              "back-to-back block in this same process; the memset of the d theta_i plane is part of it"}
-        except Exception as e:      # noqa: BLE001
-            contract = {"error": repr(e)}
-        finally:
-            F.check(L.lh_set_tuning(ctx, b""), ctx)
 
     # N > 1: what every rank measured, and what the one collective costs on its own (the in-stream
     # min all-reduce of one FT value, timed by HIP events around a block of lh_allreduce_min calls)
@@ -469,6 +478,13 @@ def main():
             traffic, traffic_source, traffic_command = tr["total_bytes"], tr.get("source"), tr.get("command")
             valu_per_cell = tr.get("valu_per_cell")
             valu_busy = tr.get("valu_busy")
+        # ... and of the contract-traffic regime (the "<workload>_nozero" PMC passes)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            trz = json.load(fh).get(a.workload + "_nozero")
+        if contract and "kernel_ms" in contract and trz and trz["ncols"] == a.ncols and trz["nlev"] == nlev:
+            contract["traffic"] = trz["total_bytes"]
+            contract["traffic_source"] = trz.get("source")
+            contract["valu_per_cell"] = trz.get("valu_per_cell")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -520,6 +536,8 @@ def main():
                      "valu_is": "PROFILED (same committed PMC passes as traffic): VALU instructions per cell-update, and the "
                                 "fraction of the launch the SIMDs spend issuing them (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / "
                                 "GRBM_GUI_ACTIVE per XCD) -- the Float64 kernels are bound by this, not by HBM"},
+        "order": "stream probe (43 launches), contract-traffic regime (65 launches), W warm-up steps, K timed steps, "
+                 "then the optional stepper blocks",
         "contract_traffic": contract,
         "ranks": ranks,
         "stable_dt_seen": dt_seen,

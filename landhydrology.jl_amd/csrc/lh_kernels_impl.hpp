@@ -706,9 +706,9 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 // with the expression of rhs_kernel (lower cell first), so the step is bitwise the
 // fused-stage one and conservation is untouched.  Two barriers per stage.
 // bcv: NULL or [nsteps][3][2][2] FT boundary values (step, stage, face, component).
-// WAVE: a column is one wavefront (nlev <= 64).  The neighbour exchange then needs no
-// workgroup barrier -- LDS operations of one wave execute in order -- so a workgroup can hold
-// many columns (wide contiguous pieces for the plane tiles) without coupling their arithmetic.
+// This thread-per-cell form serves columns of MORE than 128 levels; up to 128 levels a column is one
+// wavefront with one or two adjacent cells per lane and no workgroup barrier at all
+// (column_stepper_wave_kernel below).
 // exchange arrays per column / plane tiles of the initial fetch (the two share the dynamic LDS)
 template <int MODEL> constexpr int cs_exchange_arrays() {
     return MODEL == MODEL_COUPLED ? 5 : 2;
@@ -723,7 +723,7 @@ static inline int cs_fetch_tiles(int model, bool noice, bool need_Taux) {
     return 3; // vl, ti, rhoe (HEAT reads the first two from Ya)
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool WAVE, bool NOICE = false, bool VGF = true>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool NOICE = false, bool VGF = true>
 __global__ void __launch_bounds__(1024)
 column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
                       const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
@@ -740,15 +740,12 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const FT dt = dt_device ? *dt_device : dt_value;
     // exchange arrays of this column: (K, h) for the water, (T, kappa) for the heat, rho_e_l K for
     // both -- only what the model needs (LDS per workgroup sets how many workgroups a CU holds)
-    constexpr int NARR = cs_exchange_arrays<MODEL>() + (WAVE ? cs_flux_arrays<MODEL>() : 0);
+    constexpr int NARR = cs_exchange_arrays<MODEL>();
     FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * n;
     FT* sh = sK + n;
     FT* sT = WATER ? sh + n : sK;
     FT* sKap = sT + n;
     FT* sE = sKap + n;
-    // (WAVE) fluxes of the face below cell i: water, then heat
-    FT* sFw = reinterpret_cast<FT*>(s_dyn) + (size_t(slot) * NARR + cs_exchange_arrays<MODEL>()) * n;
-    FT* sFe = WATER ? sFw + n : sFw;
     const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
     DevParams<FT> P = P0; // boundary values change per stage
@@ -830,8 +827,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 if (HEAT) { sT[i] = T; sKap[i] = kap; }
                 if (HEAT && WATER) sE[i] = E;
             }
-            if (WAVE) wave_sync();
-            else __syncthreads();
+            __syncthreads();
             FT Fw_lo = FT(0), Fe_lo = FT(0), Fw_hi = FT(0), Fe_hi = FT(0);
             // boundary faces: the bottom thread and the top thread go through boundary_fluxes
             // TOGETHER (one divergent pass, not two, when both faces need closures)
@@ -868,7 +864,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                         Fw_hi = Fw_b;
                         Fe_hi = Fe_b;
                     }
-                } else if (!WAVE) { // (one-wave columns read the neighbour's flux below instead)
+                } else {
                     FT gh = FT(0);
                     if (WATER) {
                         gh = (sh[i + 1] - h) * cgw;
@@ -879,20 +875,6 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                         Fe_hi = -(kap + sKap[i + 1]) * gT;
                         if (WATER) Fe_hi = Fe_hi - (E + sE[i + 1]) * gh;
                     }
-                }
-            }
-            if (WAVE) {
-                // each interior face is evaluated ONCE, by the cell above it (the expression of
-                // rhs_kernel, lower cell first), and handed down through LDS: the same bits the
-                // two-sided evaluation gives, four (Richards) to ten (coupled) instructions less
-                if (i < n) {
-                    if (WATER) sFw[i] = Fw_lo;
-                    if (HEAT) sFe[i] = Fe_lo;
-                }
-                wave_sync();
-                if (i < n - 1) {
-                    if (WATER) Fw_hi = sFw[i + 1];
-                    if (HEAT) Fe_hi = sFe[i + 1];
                 }
             }
             const FT dvl = WATER ? Fw_lo - Fw_hi : FT(0);
@@ -911,13 +893,12 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             };
             if (WATER) u_vl = upd(y_vl, u_vl, dvl);
             if (HEAT) u_re = upd(y_re, u_re, dre);
-            if (WAVE) wave_sync(); // neighbours have read this stage's LDS values
-            else __syncthreads();
+            __syncthreads(); // neighbours have read this stage's LDS values
         }
         y_vl = u_vl;
         y_re = u_re;
     }
-    if (WAVE) __syncthreads(); // the tiles overlay other columns' exchange arrays
+    __syncthreads(); // the tiles overlay other columns' exchange arrays
     if (i < n) {
         if (WATER) tiles[slot * n + i] = y_vl;
         if (HEAT) tiles[tile_n + slot * n + i] = y_re;
@@ -1650,7 +1631,7 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     do {                                                                                                                               \
         if (wave && cw == 1) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv); \
         else if (wave) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
-        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, false, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);                \
+        else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);                \
     } while (0)
 #define LH_CS(F, PC, NI)                                    \
     do {                                                    \

@@ -6,13 +6,13 @@ TAG=${1:-r}
 OUT=gpurun_out/${TAG}_bench_all.jsonl
 : > $OUT
 run() { python bench.py --no-cpu-baseline "$@" >> $OUT 2>> gpurun_out/${TAG}_bench_all.err || echo "{\"failed\": \"$*\"}" >> $OUT; }
-for w in c2 c3 c4 c5 f3v64 f3c32 f3c64; do run --workload $w; done
+for w in c2 c3 c4 c5 f3v64 f3v64p f3c32 f3c64 f3c32s f3c64s; do run --workload $w; done
 run --workload c2 --no-known-zero --no-stepper
 run --workload c3 --no-known-zero --no-stepper
 run --workload c3 --placement-tune --no-stepper
 python - $OUT <<'PY'
 import json, sys
-print("%-6s %-14s %10s %8s %8s %8s %8s %6s %6s %6s %8s %8s %8s" % ("wl", "flags", "value", "ms/step", "kern", "kmin", "fused", "frac", "kfrac", "kcontr", "probe", "step", "stages"))
+print("%-7s %-14s %10s %8s %8s %8s %8s %6s %6s %8s %8s %8s %9s %7s %8s" % ("wl", "flags", "value", "ms/step", "kern", "kmin", "fused", "frac", "kfrac", "probe", "step", "stages", "contr_ms", "cfrac", "adaptive"))
 for line in open(sys.argv[1]):
     d = json.loads(line)
     if "failed" in d:
@@ -20,9 +20,12 @@ for line in open(sys.argv[1]):
     r = d["roofline"]
     wl = d["config"]["workload"].split(":")[0]
     flags = ("zero=0 " if not r["theta_i_known_zero"] and r["bytes_moved_per_cell"] >= r["bytes_per_cell"] - 1 else "") + ("tuned" if d.get("placement_tuning") else "")
-    print("%-6s %-14s %10.3e %8.4f %8.4f %8.4f %8.4f %6.3f %6.3f %6.3f %8.4f %8s %8s" % (
+    ct = d.get("contract_traffic") or {}
+    print("%-7s %-14s %10.3e %8.4f %8.4f %8.4f %8.4f %6.3f %6.3f %8.4f %8s %8s %9s %7s %8s" % (
         wl, flags, d["value"], d["ms_per_step"], r["kernel_ms"], r["kernel_ms_min"] or 0, r["fused_dt_kernel_ms"] or 0, r["frac"],
-        r["kernel_frac"], r["kernel_frac_contract_bytes"], (r["stream_probe"] or {}).get("ms", 0),
+        r["kernel_frac"], (r["stream_probe"] or {}).get("ms", 0),
         ("%.4f" % d["ssprk33"]["ms_per_step"]) if "ssprk33" in d else "-",
-        ("%.4f" % d["ssprk33_fused_stages"]["ms_per_step"]) if "ssprk33_fused_stages" in d else "-"))
+        ("%.4f" % d["ssprk33_fused_stages"]["ms_per_step"]) if "ssprk33_fused_stages" in d else "-",
+        ("%.4f" % ct["kernel_ms"]) if "kernel_ms" in ct else "-", ("%.3f" % ct["frac"]) if "frac" in ct else "-",
+        ("%.4f" % d["adaptive_ssprk33"]["ms_per_step"]) if "adaptive_ssprk33" in d else "-"))
 PY

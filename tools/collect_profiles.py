@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workloads = sys.argv[1], sys.argv[2:]
-rnd = {"r2": "round2"}.get(tag, tag)
+rnd = {"r2": "round2", "r3": "round3"}.get(tag, tag)
 out_json = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 try:
     table = json.load(open(out_json))
@@ -28,9 +28,12 @@ for w in workloads:
     summ = os.path.join(d, "summary.txt")
     text = open(summ).read()
     dst = os.path.join(ROOT, "profiles", f"{rnd}_{w}_summary.txt")
+    nozero = w.endswith("_nozero")          # the SURVEY 8(d) byte contract as traffic: LH_TUNE zero=0
+    wl = w[:-len("_nozero")] if nozero else w
+    bargs = f"--workload {wl}" + (" --no-known-zero" if nozero else "")
     with open(dst, "w") as fh:
-        fh.write(f"# bash tools/gpu_profile.sh {tag}_{w} --workload {w}   (MI355X, rocprofv3; one pass per PMC group)\n")
-        fh.write("# = python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stepper --workload " + w + "\n")
+        fh.write(f"# bash tools/gpu_profile.sh {tag}_{w} {bargs}   (MI355X, rocprofv3; one pass per PMC group)\n")
+        fh.write(f"# = python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stepper --no-contract-regime {bargs}\n")
         fh.write(text)
     for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{rnd}_{w}_kernel_stats.csv"))
@@ -53,7 +56,7 @@ for w in workloads:
     read_b = 2.0 * 1024.0 * rec["FETCH_SIZE"]       # KiB, and the gfx950 wide-read factor 2
     write_b = 1024.0 * rec["WRITE_SIZE"]
     table[w] = {
-        "ncols": ncols, "nlev": nlev, "known_zero": True,
+        "ncols": ncols, "nlev": nlev, "known_zero": not nozero,
         "read_bytes": read_b, "write_bytes": write_b, "total_bytes": read_b + write_b,
         "valu_per_cell": rec["SQ_INSTS_VALU"] * 64.0 / cells,
         "salu_per_cell": rec["SQ_INSTS_SALU"] * 64.0 / cells,
@@ -65,7 +68,7 @@ for w in workloads:
         "kernel": rec["kernel"],
         "source": f"profiles/{rnd}_{w}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, "
                   f"separate passes; FETCH_SIZE x2 gfx950 correction)",
-        "command": f"python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stepper --workload {w}",
+        "command": f"python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stepper --no-contract-regime {bargs}",
     }
     print(w, {k: table[w][k] for k in ("total_bytes", "valu_per_cell", "salu_per_cell")},
           "moved by bench:", full["roofline"]["bytes_moved_per_launch"])

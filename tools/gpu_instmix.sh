@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/mix_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-stepper --no-placement-tune $*"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-stepper --no-placement-tune --no-contract-regime $*"
 pass() { # name counters...
     local name=$1; shift
     timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $B > $OUT/bench_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/bench_$name.log; return 1; }

@@ -2,7 +2,7 @@
 # quick PMC pass: VALU instructions per launch of the dominant kernel + kernel time
 OUT=$GRAFT_REPO_ROOT/gpurun_out/valu_$1; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-stepper $* > $OUT/bench.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-stepper --no-contract-regime $* > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
