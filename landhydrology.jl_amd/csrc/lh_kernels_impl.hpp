@@ -53,7 +53,11 @@ template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int MOD
 constexpr bool f32_coupled_vgpr_constants() {
     if (MODEL != MODEL_COUPLED || PERCOL || !M::is_production || !(MODE == 0 || MODE == 4)) return false;
     if (sizeof(FT) == 4 && MODE == 4) return LH_F32C_DT_VGPRCONST != 0;
-    return sizeof(FT) == 8 || !FACTORS; // Float64 (no occupancy bound there): +2.5 % on f3c64
+    // Float64: without conductivity factors only.  (Round 2 pinned the factors kernels too, +2.5 % at 127
+    // VGPRs + 12 B of scratch; with the round-3 closures the pinned tendency kernel needs 154 VGPRs --
+    // 3 waves, 0.61 ms on f3c64 -- or spills 76 B at 4 waves, 0.67 ms; unpinned it fits 119 VGPRs at 4
+    // waves without scratch and takes 0.58 ms, v_readlane reloads of spilled uniforms and all.)
+    return !FACTORS;
 }
 
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, bool NOICE>
@@ -73,10 +77,10 @@ constexpr int rhs_waves_per_simd() {
 #define LH_F64_FACTORS_STAGE_WAVES4 0
 #endif
 #ifndef LH_F64_FACTORS_TEND_WAVES
-#define LH_F64_FACTORS_TEND_WAVES 3
+#define LH_F64_FACTORS_TEND_WAVES 4
 #endif
-    // (round 3: the tendency kernel now needs 154 VGPRs unconstrained; bounded to 127 it spills 84 B per
-    // lane to scratch and runs 0.75 instead of 0.53 ms -- 3 waves/SIMD, no scratch)
+    // (round 3: with its column constants pinned in VGPRs the tendency kernel needs 154; they are left to
+    // the SGPR file now, see f32_coupled_vgpr_constants)
     if (M::is_production && FACTORS && sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && !PERCOL &&
         (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return LH_F64_FACTORS_TEND_WAVES;
     if (!M::is_production || FACTORS) return 1;

@@ -5,7 +5,7 @@
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/landhydrology.jl_amd/csrc
+src=${SRC:-$root/landhydrology.jl_amd/csrc}
 out=$root/landhydrology.jl_amd/lib/variants
 tmp=$(mktemp -d /tmp/lh_variant.XXXXXX)
 mkdir -p "$out"
