@@ -1602,6 +1602,35 @@ void launch_rhs_for_model(const DevParams<FT>& P, const Planes<FT>& in, const Pl
         launch_rhs_model<FT, MODEL, MathFast<FT>>(P, in, aux, base, out, dt, dt_dev, mode, factors, percol, noice, tune, s);
 }
 
+// Columns (= waves) per workgroup of column_stepper_wave_kernel.  Whole multiples of 4, so the four
+// SIMDs of a CU carry the same number of waves (measured on 1e6 x 64 Float64 columns, ms per step:
+// 8 columns 0.60, 9..11 0.72..0.85, 12 0.56, 13 0.85, 14 0.79, 16 0.71), and among 4 / 8 / 12 the
+// count that keeps most waves resident under the instantiation's register count and the LDS of a
+// CU (48 KiB of math tables per Float64 workgroup + the exchange arrays of its columns): 12 for
+// Float64 Richards without ice (63 / 77 VGPRs, 6 waves per SIMD), 8 for the per-column-parameter
+// and ice kernels (94+ VGPRs: a second 768-thread workgroup would not fit), 4 for Float32.
+// Small ensembles take 4 to spread over the CUs.
+template <auto Kernel>
+unsigned wave_stepper_columns(int64_t ncols, size_t dyn_col) {
+    static const hipFuncAttributes attr = [] {
+        hipFuncAttributes a{};
+        if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(Kernel)) != hipSuccess) a.numRegs = 0;
+        return a;
+    }();
+    if (ncols < 4096 || attr.numRegs <= 0) return 4u;
+    const unsigned regs = (unsigned(attr.numRegs) + 7u) & ~7u;
+    const unsigned waves_cu = 4u * (512u / regs < 8u ? 512u / regs : 8u);
+    unsigned best = 4u, best_resident = 0u;
+    for (unsigned c = 4u; c <= 12u; c += 4u) {
+        const size_t lds = attr.sharedSizeBytes + c * dyn_col;
+        const unsigned by_lds = unsigned((size_t(160) << 10) / (lds ? lds : 1));
+        const unsigned by_regs = waves_cu / c;
+        const unsigned resident = c * (by_lds < by_regs ? by_lds : by_regs);
+        if (resident > best_resident) best = c, best_resident = resident;
+    }
+    return best;
+}
+
 template <typename FT, int MODEL>
 void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y, const Planes<FT>& aux,
                                      FT dt, const FT* dt_dev, int64_t nsteps, const FT* bcv, bool factors,
@@ -1611,28 +1640,31 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     const int cw = (P.nlev + 63) / 64;
     const bool wave = cw <= 2;
     const unsigned tpc = wave ? 64u : (unsigned)((P.nlev + 63) / 64 * 64);
-    // columns per workgroup: 8 one-wave columns (64-byte pieces of every plane row: tile I/O 0.43
-    // instead of 0.79 ms on 1e6 x 64 Float64, tools/microbench/tile_io_probe.hip); 256 threads when
-    // the stages need workgroup barriers.
-    // The Float64 math tables take 48 KiB of LDS per workgroup whatever its size, so large
-    // ensembles of Float64 columns run 512-thread workgroups (2 per CU; measured on 1e6 columns:
-    // 64 levels 0.75 / 0.68 / 0.78 ms per step with 256 / 512 / 1024 threads)
-    unsigned cpb = wave ? 8u : (256u / tpc ? 256u / tpc : 1u);
+    // columns per workgroup of the thread-per-cell kernel: 256 threads, 512 for large Float64
+    // ensembles (the Float64 math tables take 48 KiB of LDS per workgroup whatever its size);
+    // the wave kernel picks its own from the instantiation's registers (wave_stepper_columns)
+    unsigned cpb = 256u / tpc ? 256u / tpc : 1u;
     if (sizeof(FT) == 8 && P.ncols >= 4096) cpb = 512u / tpc ? 512u / tpc : 1u;
-    if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;
-    dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);
     const bool need_Taux = (MODEL == MODEL_RICHARDS) && factors && P.viscosity_kind;
     const int tiles = cs_fetch_tiles(MODEL, noice && !factors, need_Taux);
     // dynamic LDS: the plane tiles of the initial fetch and the exchange arrays share it
     const int narr = cs_exchange_arrays<MODEL>() + (wave ? cs_flux_arrays<MODEL>() : 0);
     const size_t ex_words = wave ? (size_t)narr * 64 : (size_t)narr * (size_t)P.nlev;
     const size_t tile_words = (size_t)tiles * (size_t)P.nlev;
-    const unsigned dyn = (unsigned)(cpb * (ex_words > tile_words ? ex_words : tile_words) * sizeof(FT));
+    const size_t dyn_col = (ex_words > tile_words ? ex_words : tile_words) * sizeof(FT);
     using M = MathFast<FT>;
     constexpr bool has_robust = M::uses_tables && MODEL != MODEL_HEAT; // (as launch_rhs_model)
     const bool robust = has_robust && P.vg_fast_all == 0;
 #define LH_CS_GO(F, PC, NI, VG)                                                                                                        \
     do {                                                                                                                               \
+        if (wave && cw == 1) {                                                                                                         \
+            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>>(P.ncols, dyn_col);                  \
+        } else if (wave) {                                                                                                             \
+            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>>(P.ncols, dyn_col);                  \
+        }                                                                                                                              \
+        if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;                                               \
+        const dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);                                                             \
+        const unsigned dyn = (unsigned)(cpb * dyn_col);                                                                                \
         if (wave && cw == 1) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv); \
         else if (wave) hipLaunchKernelGGL((column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);      \
         else hipLaunchKernelGGL((column_stepper_kernel<FT, MODEL, F, PC, M, NI, VG>), g, b, dyn, s, P, Y, aux, dt, dt_dev, nsteps, bcv);                \
