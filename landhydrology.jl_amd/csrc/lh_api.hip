@@ -641,26 +641,44 @@ void state_free(lh_ctx* c, lh_state* s) {
     delete s;
 }
 
-// The persistent column stepper (workgroup = columns, thread = cell) keeps the state in
-// registers over all steps of a call: 0.71 ms per step on 1e6 x 64 Float64 columns against
-// 1.06 ms for three fused-stage launches, and 2-3 us per step for a single column.  Getting
-// the level-fastest registers from and to the column-fastest planes costs ~0.7 ms per call at
-// that size, so large ensembles take it from 3 steps per call on (and only without Dirichlet
-// faces, see below); small ones (<= 2^20 threads) always.  Not for columns with more levels than a workgroup has threads.
+// The persistent column stepper keeps the state in registers over all steps of a call: 0.56 ms per
+// step on 1e6 x 64 Float64 columns against 0.82 ms for three fused-stage launches, and 2-3 us per
+// step for a single column.  Getting the level-fastest registers from and to the column-fastest
+// planes costs about one step per call at that size, so large ensembles take it from 3 steps per call
+// on; small ones (<= 2^20 threads) always.  Not for columns with more levels than a workgroup has threads.
 // LH_TUNE=persist=0: never (fused-stage launches), persist=2: always.
-bool use_column_stepper(const lh_ctx* c, int64_t nsteps) {
+// A Dirichlet face needs the closures of the face state.  rhs_kernel evaluates them for 64 columns
+// at once; in the stepper the one lane next to the face does, with its whole wave waiting: a second
+// closure pass per stage.  The wave stepper (<= 128 levels) evaluates them ONCE per call when the
+// boundary values are constant over the call and nothing else the face state reads moves (the rule
+// of face_state_is_static, lh_closures.hpp, restated here); otherwise large ensembles with a
+// Dirichlet face stay with the fused-stage launches.
+static bool dirichlet_faces_are_hoisted(const lh_ctx* c, bool bcv) {
+    const bool water = c->cfg.model != LH_MODEL_HEAT, heat = c->cfg.model != LH_MODEL_RICHARDS;
+    bool any = false, all_static = true;
+    for (int f = 0; f < 2; ++f) {
+        const int kh = c->hp.bc_kind[f][LH_COMP_HYDROLOGY], ke = c->hp.bc_kind[f][LH_COMP_ENERGY];
+        const bool needs_w = water && kh == LH_BC_DIRICHLET, needs_k = heat && ke == LH_BC_DIRICHLET;
+        any = any || needs_w || needs_k;
+        if (needs_w && c->hp.viscosity_kind != LH_FACTOR_NONE && heat && ke != LH_BC_DIRICHLET) all_static = false;
+        if (needs_k && water && kh != LH_BC_DIRICHLET) all_static = false;
+    }
+    if (!any) return true;
+    // (measured, 1e6 columns, ms per step, stepper vs fused stages: Richards with a viscosity factor
+    // 0.80 vs 1.05; the coupled model with both conductivity factors and ice, where the closures and not
+    // the planes' traffic bound either engine, 0.749 vs 0.753 in Float32 and 2.03 vs 1.97 in Float64)
+    const bool factors = c->hp.viscosity_kind != LH_FACTOR_NONE || c->hp.impedance_kind != LH_FACTOR_NONE;
+    if (c->cfg.model == LH_MODEL_COUPLED && factors && c->cfg.dtype == LH_F64) return false;
+    return all_static && !bcv && c->cfg.nlev <= 128;
+}
+
+bool use_column_stepper(const lh_ctx* c, int64_t nsteps, bool bcv = false) {
     if (c->tune.persist == 0 || c->cfg.nlev > 1024) return false;
     if (c->hp.atmos_on) return false; // the surface fluxes are re-evaluated before every stage launch
     if (c->tune.persist == 2) return true;
     const int64_t threads = c->cfg.ncols * int64_t((c->cfg.nlev + 63) / 64 * 64);
     if (threads <= (int64_t(1) << 20)) return true;
-    // A Dirichlet face needs the closures of the face state.  rhs_kernel evaluates them for 64
-    // columns at once; here the one thread next to the face does, with its whole wave waiting:
-    // a second closure pass per stage (3.6 vs 2.1 ms per step on the f3c64 workload).  Large
-    // ensembles with a Dirichlet face stay with the fused-stage launches.
-    for (int f = 0; f < 2; ++f)
-        for (int k = 0; k < 2; ++k)
-            if (c->hp.bc_kind[f][k] == LH_BC_DIRICHLET) return false;
+    if (!dirichlet_faces_are_hoisted(c, bcv)) return false;
     return nsteps >= 3;
 }
 
@@ -1522,7 +1540,7 @@ int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double
     (void)hipSetDevice(c->device);
     // Default: all nsteps in ONE launch of the persistent column stepper (state in registers,
     // no plane traffic between stages or steps; column_stepper_kernel)
-    if (use_column_stepper(c, nsteps)) return run_column_stepper(c, Y, Ya, dt, nullptr, nsteps, bcv);
+    if (use_column_stepper(c, nsteps, bcv != nullptr)) return run_column_stepper(c, Y, Ya, dt, nullptr, nsteps, bcv);
     // the stage state carries no theta_i plane: the fused stages read theta_i from Y
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
@@ -1610,7 +1628,7 @@ int lh_step_ssprk33_device_dt(lh_ctx* c, lh_state* Y, const lh_state* Ya, double
     if ((rc = check_state(c, Y, pm, "Y"))) return rc;
     if ((rc = check_state(c, Ya, aux_mask(c), "Ya"))) return rc;
     (void)hipSetDevice(c->device);
-    if (use_column_stepper(c, 1)) return run_column_stepper(c, Y, Ya, 0.0, dt_device_ft, 1, bcv);
+    if (use_column_stepper(c, 1, bcv != nullptr)) return run_column_stepper(c, Y, Ya, 0.0, dt_device_ft, 1, bcv);
     if (!c->scratch_u1 && (rc = state_alloc(c, pm & ~LH_MASK(LH_VAR_THETA_I), &c->scratch_u1))) return rc;
     lh_state* U1 = c->scratch_u1;
     lh_state* U2 = U1;

@@ -156,13 +156,13 @@ __device__ __forceinline__ void water_closures_pow(const M& mm, const DevParams<
 // NOICE: the ice plane of the state is known to be all zeros (lh_state zero bits): ti is the
 // literal 0, nu_eff == nu, and the separate psi saturation never exists -- the same numbers as
 // the general path produces for ti == 0, with the ice code compiled out.
-// -psi / q in Float32 (v_cvt_f32_f64 x2, v_rcp_f32, v_mul_f32 with a negated operand), kept finite:
+// -psi / q in Float32 (v_cvt_f32_f64 x2, v_rcp_f32, v_mul_f32), kept finite:
 // a bone-dry cell of a clay-like soil has |psi| beyond the Float32 range while its K underflows to 0,
 // and 0 x Inf would poison the column's maximum (the value is non-negative: an integer minimum of the
 // bit patterns clamps Inf -- and a NaN -- to FLT_MAX)
 template <typename FT>
-__device__ __forceinline__ float slope32(FT psi, FT q) {
-    const float s = -float(psi) * __builtin_amdgcn_rcpf(float(q));
+__device__ __forceinline__ float slope32(FT npsi, FT q) { // npsi = -psi
+    const float s = float(npsi) * __builtin_amdgcn_rcpf(float(q));
     return __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(int, s), 0x7f7fffff));
 }
 
@@ -175,6 +175,15 @@ __device__ __forceinline__ void finish_colc(const M& mm, ColC<FT>& c) {
     c.l2_por = (M::is_production && por > FT(0)) ? mm.log2(por) : FT(0);
 }
 
+// h_hi - h_lo of two vertically adjacent cell centres (h = psi + z, the hydraulic head of
+// right_hand_side.jl:141 / :333) from the NEGATED potentials the closures hand out (NEGPSI): the grid
+// is uniform (make_grid), so z_hi - z_lo is the constant dz -- the heads themselves are never formed,
+// and |psi| >> z does not cost the gravity term its low bits
+template <typename FT>
+__device__ __forceinline__ FT head_difference(FT npsi_hi, FT npsi_lo, FT dz) {
+    return (npsi_lo - npsi_hi) + dz; // (-a) - (-b) = b - a exactly
+}
+
 // every active lane of the wave has the predicate (one s_and/s_cmp on the ballot)
 __device__ __forceinline__ bool wave_all(bool pred) {
     return __builtin_amdgcn_ballot_w64(!pred) == 0ull;
@@ -185,8 +194,11 @@ __device__ __forceinline__ bool wave_all(bool pred) {
 // BRANCHY: the saturated cells are a divergent branch around the power chain (few live registers:
 // the Float64 coupled kernels are register-bound) instead of every lane running the chain and a
 // wave-level repair (fewest instructions: the Richards kernels are issue-bound).  Same values.
+// NEGPSI: `psi` receives -psi (>= 0 where unsaturated).  Every branch below forms -psi anyway (it is
+// the 2^(.) itself), and a caller that only differences psi (head_difference) or negates once per
+// column (boundary faces) then never spends an instruction per cell on the sign.
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false,
-          bool BRANCHY = false>
+          bool BRANCHY = false, bool NEGPSI = false>
 __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<FT>& P,
                                                    const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                    FT& psi, float* dpsi = nullptr, bool vgfast = false) {
@@ -242,6 +254,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         return mm.exp2_scaled(x * y);
     };
     FT L, Kb;
+    FT npsi = FT(0); // -psi
     if constexpr (BRANCHY) {
         L = FT(0); // log2 S of an unsaturated cell (0 otherwise: K_r = 1, and sqrt(S) = 2^0 below)
         if (unsat) {
@@ -253,8 +266,8 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner);
             if (!RELK) Kb = Kb * c.Ksat;
             if (WANT_PSI && shared) {
-                psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
-                if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+                npsi = ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
+                if (WANT_DPSI) *dpsi = slope32<FT>(npsi, w * num);
             }
         } else {
             // (saturated cells are rare: the empty asm keeps this a real branch -- otherwise the
@@ -263,7 +276,7 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             if (WANT_PSI && shared) {
                 FT vin = vl; // (opaque INPUT: nothing of the saturated evaluation can move above the branch)
                 asm volatile("" : "+v"(vin));
-                psi = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
+                npsi = (S == FT(1)) ? FT(0) : (nu_eff - vin) * c.inv_S_s; // -((vl - nu_eff)/S_s), exactly
                 if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
             }
         }
@@ -279,8 +292,8 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
         Kb = FACTORS ? inner * inner : mm.sqrt_mul(S, inner * inner); // K without the conductivity factors (FACTORS: without sqrt(S) too)
         if (!RELK) Kb = Kb * c.Ksat;
         if (WANT_PSI && shared) {
-            psi = -ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
-            if (WANT_DPSI) *dpsi = slope32<FT>(psi, w * num);
+            npsi = ex2(fma_ft(fma_ft(Lw, c.e_one, -a), c.e_inv_n, -c.e_log2_alpha));
+            if (WANT_DPSI) *dpsi = slope32<FT>(npsi, w * num);
         }
         if (__builtin_amdgcn_ballot_w64(!unsat) != 0ull) { // (a NaN saturation lands here too, as in the reference's `S < 1 ? ... : ...`)
             FT vin = vl; // (opaque: the compiler must not turn this block into per-cell selects)
@@ -288,8 +301,8 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             L = unsat ? L : FT(0);   // K_r = 1, and sqrt(S) = 2^0 in the factor product below
             Kb = unsat ? Kb : (RELK ? FT(1) : c.Ksat);
             if (WANT_PSI && shared) {
-                const FT ps = (S == FT(1)) ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
-                psi = unsat ? psi : ps;
+                const FT nps = (S == FT(1)) ? FT(0) : (nu_eff - vin) * c.inv_S_s; // -(vl - nu_eff)/S_s, exactly
+                npsi = unsat ? npsi : nps;
                 if (WANT_DPSI) *dpsi = unsat ? *dpsi : float(c.n * c.m * c.inv_S_s);
             }
         }
@@ -301,15 +314,15 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
             const FT ae = Le * c.e_inv_m;
             const FT we = FT(1) - ex2(ae);
             const FT Lwe = mm.log2(we);
-            psi = -ex2(fma_ft(fma_ft(Lwe, c.e_one, -ae), c.e_inv_n, -c.e_log2_alpha));
-            if (WANT_DPSI) *dpsi = slope32<FT>(psi, we * num);
+            npsi = ex2(fma_ft(fma_ft(Lwe, c.e_one, -ae), c.e_inv_n, -c.e_log2_alpha));
+            if (WANT_DPSI) *dpsi = slope32<FT>(npsi, we * num);
         } else {
             const bool one = (same & (S == FT(1))) | (!same & (num == por_e));
             FT vin = vl;
             asm volatile("" : "+v"(vin));
-            FT ps = one ? -FT(0) : (vin - nu_eff) * c.inv_S_s;
-            if (por_e < FT(0)) ps = FT(NAN); // Se < 0: `^` raises DomainError in the reference
-            psi = ps;
+            FT nps = one ? FT(0) : (nu_eff - vin) * c.inv_S_s;
+            if (por_e < FT(0)) nps = FT(NAN); // Se < 0: `^` raises DomainError in the reference
+            npsi = nps;
             if (WANT_DPSI) *dpsi = float(c.n * c.m * c.inv_S_s);
         }
     }
@@ -326,17 +339,18 @@ __device__ __forceinline__ void water_closures_log(const M& mm, const DevParams<
     } else {
         K = Kb;
     }
+    if (WANT_PSI) psi = NEGPSI ? npsi : -npsi;
     // (nu <= theta_r, a DomainError in the reference, is poisoned per column in make_colc)
 }
 
 template <typename FT, typename M, bool FACTORS, bool WANT_PSI = true, bool WANT_DPSI = false, bool NOICE = false, bool RELK = false,
-          bool BRANCHY = false>
+          bool BRANCHY = false, bool NEGPSI = false>
 __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>& P,
                                                const ColC<FT>& c, FT vl, FT ti, FT T, FT& K,
                                                FT& psi, float* dpsi = nullptr, bool vgfast = false) {
     static_assert(!RELK || M::is_production, "the relative-conductivity form exists for the production math only");
     if (M::is_production) {
-        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE, RELK, BRANCHY>(mm, P, c, vl, ti, T, K, psi, dpsi, vgfast);
+        water_closures_log<FT, M, FACTORS, WANT_PSI, WANT_DPSI, NOICE, RELK, BRANCHY, NEGPSI>(mm, P, c, vl, ti, T, K, psi, dpsi, vgfast);
     } else {
         water_closures_pow<FT, M, FACTORS, WANT_PSI>(mm, P, c, vl, ti, T, K, psi);
         if (WANT_DPSI) { // as the oracle writes it
@@ -349,6 +363,7 @@ __device__ __forceinline__ void water_closures(const M& mm, const DevParams<FT>&
             else
                 *dpsi = float(c.n * c.m / c.S_s);
         }
+        if (NEGPSI && WANT_PSI) psi = -psi;
     }
 }
 
@@ -457,12 +472,19 @@ __device__ __forceinline__ FT temperature_closure(const M& mm, const DevParams<F
 // methods :295-444.  (vl_c, ti_c, T_c, K_c, psi_c) are the centre values next
 // to the face; K_c/psi_c are the values the interior stage already computed
 // (the reference recomputes them on a 2-element array: same numbers).
+// Two parts: face_state evaluates the closures of the FACE state of a Dirichlet component (the only
+// expensive part: a full water and/or kappa closure), boundary_fluxes_from assembles the two fluxes
+// from it.  The persistent steppers evaluate the first part once per call when nothing it reads
+// changes during the call (face_state_is_static).
+template <typename FT>
+struct FaceState {
+    FT K, psi, kap, T; // K(face state), psi(face state), kappa(face state), T of the face state
+};
+
 template <typename FT, typename M, int MODEL, bool FACTORS, bool NOICE = false>
-__device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>& P,
-                                                const ColC<FT>& c, int face, int64_t col, FT vl_c,
-                                                FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
-                                                FT& f_w, FT* K_face = nullptr,
-                                                FT* kappa_face = nullptr, bool vgfast = false) {
+__device__ __forceinline__ FaceState<FT> face_state(const M& mm, const DevParams<FT>& P, const ColC<FT>& c,
+                                                    int face, int64_t col, FT vl_c, FT ti_c, FT T_c,
+                                                    bool vgfast = false) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
     const int ke = P.bc_kind[face][COMP_ENERGY];
@@ -470,23 +492,59 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
     FT ve = P.bc_value[face][COMP_ENERGY], vh = P.bc_value[face][COMP_HYDROLOGY];
     if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
     if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
-
-    FT vl_f = vl_c, T_f = T_c; // face := centre (:218-228)
-    if (HEAT && ke == BC_DIRICHLET) T_f = ve;
+    FaceState<FT> fs;
+    fs.K = fs.psi = fs.kap = FT(0);
+    FT vl_f = vl_c; // face := centre (:218-228)
+    fs.T = T_c;
+    if (HEAT && ke == BC_DIRICHLET) fs.T = ve;
     if (WATER && kh == BC_DIRICHLET) vl_f = vh;
+    if (HEAT && ke == BC_DIRICHLET) fs.kap = kappa_closure<FT, M, NOICE>(mm, P, c, vl_f, ti_c); // :416-444
+    if (WATER && kh == BC_DIRICHLET)                                                            // :371-401
+        water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, vl_f, ti_c, fs.T, fs.K, fs.psi, nullptr, vgfast);
+    return fs;
+}
+
+// what face_state reads besides the boundary values: the centre's vartheta_l (when the hydrology
+// component is not Dirichlet, for kappa), its theta_i (never changes) and its T (through the viscosity
+// factor, when the energy component is not Dirichlet).  True when none of that changes while a model
+// steps with constant boundary values -- the face state's closures are then constants of the call.
+template <typename FT, int MODEL, bool FACTORS>
+__device__ __forceinline__ bool face_state_is_static(const DevParams<FT>& P, int face) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    const int ke = P.bc_kind[face][COMP_ENERGY];
+    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
+    const bool needs_w = WATER && kh == BC_DIRICHLET, needs_k = HEAT && ke == BC_DIRICHLET;
+    bool ok = true;
+    if (needs_w && FACTORS && P.viscosity_kind && HEAT && ke != BC_DIRICHLET) ok = false; // T_f = T_c moves
+    if (needs_k && WATER && kh != BC_DIRICHLET) ok = false;                                // vl_f = vl_c moves
+    return ok;
+}
+
+// the T of the face state (the value face_state puts into FaceState::T)
+template <typename FT, int MODEL>
+__device__ __forceinline__ FT face_state_T(const DevParams<FT>& P, int face, int64_t col, FT T_c) {
+    if (MODEL == MODEL_RICHARDS || P.bc_kind[face][COMP_ENERGY] != BC_DIRICHLET) return T_c;
+    return P.bc_pc[face][COMP_ENERGY] ? P.bc_pc[face][COMP_ENERGY][col] : P.bc_value[face][COMP_ENERGY];
+}
+
+template <typename FT, int MODEL>
+__device__ __forceinline__ void boundary_fluxes_from(const DevParams<FT>& P, const FaceState<FT>& fs, int face,
+                                                     int64_t col, FT T_c, FT K_c, FT psi_c, FT& f_e, FT& f_w) {
+    constexpr bool WATER = (MODEL != MODEL_HEAT);
+    constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
+    const int ke = P.bc_kind[face][COMP_ENERGY];
+    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
+    FT ve = P.bc_value[face][COMP_ENERGY], vh = P.bc_value[face][COMP_HYDROLOGY];
+    if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
+    if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
     const FT dzb = P.half_dz;
     const FT sgn = (face == FACE_BOTTOM) ? FT(-1) : FT(1);
-
     f_e = FT(0);
     f_w = FT(0);
     if (HEAT) {
-        if (ke == BC_FLUX) {
-            f_e = ve;
-        } else if (ke == BC_DIRICHLET) { // :416-444
-            FT kap_f = kappa_closure<FT, M, NOICE>(mm, P, c, vl_f, ti_c);
-            f_e = sgn * (-kap_f * (T_f - T_c) / dzb);
-            if (kappa_face) *kappa_face = kap_f;
-        }
+        if (ke == BC_FLUX) f_e = ve;
+        else if (ke == BC_DIRICHLET) f_e = sgn * (-fs.kap * (fs.T - T_c) / dzb); // :416-444
     }
     if (WATER) {
         if (kh == BC_FLUX) {
@@ -494,15 +552,24 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
         } else if (kh == BC_FREE_DRAINAGE) { // :328-356
             f_w = -K_c;
         } else if (kh == BC_DIRICHLET) { // :371-401
-            FT K_f, psi_f;
-            water_closures<FT, M, FACTORS, true, false, NOICE>(mm, P, c, vl_f, ti_c, T_f, K_f, psi_f, nullptr, vgfast);
-            if (K_face) *K_face = K_f;
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
-                f_w = K_f * (psi_f - psi_c - dzb) / dzb;
+                f_w = fs.K * (fs.psi - psi_c - dzb) / dzb;
             else
-                f_w = sgn * (-K_f * (psi_f - psi_c + dzb) / dzb);
+                f_w = sgn * (-fs.K * (fs.psi - psi_c + dzb) / dzb);
         }
     }
+}
+
+template <typename FT, typename M, int MODEL, bool FACTORS, bool NOICE = false>
+__device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>& P,
+                                                const ColC<FT>& c, int face, int64_t col, FT vl_c,
+                                                FT ti_c, FT T_c, FT K_c, FT psi_c, FT& f_e,
+                                                FT& f_w, FT* K_face = nullptr,
+                                                FT* kappa_face = nullptr, bool vgfast = false) {
+    const FaceState<FT> fs = face_state<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, face, col, vl_c, ti_c, T_c, vgfast);
+    if (K_face && MODEL != MODEL_HEAT && P.bc_kind[face][COMP_HYDROLOGY] == BC_DIRICHLET) *K_face = fs.K;
+    if (kappa_face && MODEL != MODEL_RICHARDS && P.bc_kind[face][COMP_ENERGY] == BC_DIRICHLET) *kappa_face = fs.kap;
+    boundary_fluxes_from<FT, MODEL>(P, fs, face, col, T_c, K_c, psi_c, f_e, f_w);
 }
 
 } // namespace lh

@@ -5,7 +5,7 @@
 // column index fastest, so a wavefront reads 64*CPL consecutive columns of one
 // level in one fully coalesced instruction (CPL = 1 for Float64, 2 for Float32:
 // 8 B per lane either way).  One lane owns CPL whole columns
-// and marches bottom -> top, carrying K, h (T, kappa, rho_e_l K) of the previous
+// and marches bottom -> top, carrying K, -psi (T, kappa, rho_e_l K) of the previous
 // cell and the previous face flux in registers: each face flux is computed once
 // and differenced, which keeps the discrete mass/energy conservation the
 // reference's equilibrium tests rely on (coupled.jl:117, richards_equation.jl:94).
@@ -305,19 +305,15 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     const FT dt = (!TEND && dt_device) ? *dt_device : dt_value; // MODE 4: dt_value = courant
     __shared__ double s_tab[M::uses_tables ? MATH_TAB_DOUBLES : 2];
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    FT* s_zc = reinterpret_cast<FT*>(s_dyn);
     const int n = P.nlev;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s_zc[i] = P.zc[i];
-    // MODE 4: one LDS word per thread for the wave-level maximum of the face diffusivities
-    // (after the level coordinates, 16-byte aligned); lanes past the last column leave the
-    // neutral 0 there
-    float* s_red = reinterpret_cast<float*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)));
+    // MODE 4: one LDS word per thread for the wave-level maximum of the face diffusivities; lanes
+    // past the last column leave the neutral 0 there
+    float* s_red = reinterpret_cast<float*>(s_dyn);
     if (WANT_DT) s_red[threadIdx.x] = 0.0f;
-    // level-uniform prescribed fields of Ya (DevParams::aux_prof), staged behind z and the reduction
+    // level-uniform prescribed fields of Ya (DevParams::aux_prof), staged behind the reduction
     // words: T for the Richards viscosity factor, vartheta_l and theta_i for the heat-only model
     constexpr bool MAY_PROF = (MODEL == MODEL_HEAT) || (MODEL == MODEL_RICHARDS && FACTORS);
-    FT* s_pf = reinterpret_cast<FT*>(s_dyn + ((size_t(n) * sizeof(FT) + 15) & ~size_t(15)) +
-                                     (WANT_DT ? ((size_t(blockDim.x) * sizeof(float) + 15) & ~size_t(15)) : 0));
+    FT* s_pf = reinterpret_cast<FT*>(s_dyn + (WANT_DT ? ((size_t(blockDim.x) * sizeof(float) + 15) & ~size_t(15)) : 0));
     const FT* pf_T = (MAY_PROF && MODEL == MODEL_RICHARDS) ? P.aux_prof[3] : nullptr;
     const FT* pf_vl = (MAY_PROF && MODEL == MODEL_HEAT) ? P.aux_prof[0] : nullptr;
     const FT* pf_ti = (MAY_PROF && MODEL == MODEL_HEAT) ? P.aux_prof[1] : nullptr;
@@ -384,6 +380,9 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
         colj[j] = col0 + j < P.ncols ? col0 + j : P.ncols - 1;
         c[j] = make_colc<FT, M>(P, colj[j], PERCOL);
         if (WATER && !NOICE) finish_colc<FT, M>(mm, c[j]);
+        // (psi's exponent is an fma of two column constants: one of them has to sit in a VGPR anyway --
+        // pinned here, it is not re-materialised from its SGPR pair in front of every use)
+        if constexpr (M::uses_tables && WATER && !PERCOL && !HEAT) asm volatile("" : "+v"(c[j].e_log2_alpha));
     }
     // Float32 coupled tendency: with every uniform constant in SGPRs the kernel spills 45 of them
     // to VGPR lanes (28 v_readlane per two cells).  Thirteen column constants held in VGPRs
@@ -419,7 +418,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     FT kv_n[PF][CPL], ke_n[PF][CPL];               // MODE 5: k1 of those levels
     FT vl_p[CPL], re_p[CPL];                       // previous cell inputs (fused stages)
     FT yv[CPL], ye[CPL], yv_p[CPL], ye_p[CPL];     // MODE 5: Y of the current / previous cell (the stage's base)
-    FT K_p[CPL], h_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
+    FT K_p[CPL], psi_p[CPL], T_p[CPL], kap_p[CPL], E_p[CPL];
     FT Fw_lo[CPL], Fe_lo[CPL];
     FT nf_acc = FT(0); // += 0 * tendency: becomes NaN once any tendency is non-finite
     // MODE 4: stable-step bookkeeping, in Float32 whatever FT is (see slope32): n m d psi / d vl
@@ -431,7 +430,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        K_p[j] = h_p[j] = psi_p[j] = T_p[j] = kap_p[j] = E_p[j] = Fw_lo[j] = Fe_lo[j] = FT(0);
+        K_p[j] = psi_p[j] = T_p[j] = kap_p[j] = E_p[j] = Fw_lo[j] = Fe_lo[j] = FT(0);
         vl_p[j] = re_p[j] = FT(0);
         yv[j] = ye[j] = yv_p[j] = ye_p[j] = FT(0);
         vl[j] = ti[j] = re[j] = FT(0);
@@ -549,15 +548,18 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 if (HEAT) re[j] = ye[j] + dt * ke_n[k][j];
             }
         }
-        if (i + PF < i_end) fetch(k); // keep PF levels in flight ahead of the one computed
-        const FT z = s_zc[i]; // (through the scalar cache instead: 0..0.5 %, not worth a second path)
-        FT K[CPL], h[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], rcs[CPL];
+        // keep PF levels in flight ahead of the one computed.  (Refilling the slot only AFTER the cell's
+        // closures, so that the load lands in the registers they free and the ring needs no moves,
+        // was measured: -1 instruction per cell but the prefetch distance shrinks by a cell -- C2 +2 %,
+        // the HBM-bound Float32 C3 +5 % slower; with 4 levels in flight -1 % at twice the code.)
+        if (i + PF < i_end) fetch(k);
+        FT K[CPL], psi[CPL], T[CPL], kap[CPL], E[CPL], rcs[CPL];
         float dpsi[CPL], ircs[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             T[j] = Ta[j];
             kap[j] = FT(0);
-            K[j] = psi[j] = h[j] = E[j] = FT(0);
+            K[j] = psi[j] = E[j] = FT(0);
             dpsi[j] = ircs[j] = 0.0f;
             rcs[j] = FT(1);
             if (HEAT) {
@@ -566,9 +568,9 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 if (WANT_DT) ircs[j] = float(mm.rcp(rcs[j])); // (the reciprocal temperature_closure formed)
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE, RELK, HEAT>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
-                                                                                 psi[j], &dpsi[j], vgf);
-                h[j] = psi[j] + z;
+                // (psi[], psi_p[] hold -psi: see head_difference)
+                water_closures<FT, M, FACTORS, true, WANT_DT, NOICE, RELK, HEAT, true>(mm, P, c[j], vl[j], ti[j], T[j], K[j],
+                                                                                       psi[j], &dpsi[j], vgf);
                 if (HEAT) E[j] = (P.rhocp_l * (T[j] - P.T_ref)) * K[j]; // rho_e_int_l * K (:364)
             }
             if (WANT_DT && i > i_first) { // the rule of stable_dt_kernel per interior face (x 2)
@@ -582,7 +584,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 FT K_f = FT(0), kap_f = FT(0);
                 const FT K_c = K[j] * Ksc[j]; // the true conductivity of the boundary cell
                 boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_BOTTOM, colj[j], vl[j], ti[j],
-                                                              T[j], K_c, psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f, vgf);
+                                                              T[j], K_c, -psi[j], Fe_lo[j], Fw_lo[j], &K_f, &kap_f, vgf);
                 Fe_lo[j] = Fe_lo[j] * P.inv_dz;
                 Fw_lo[j] = Fw_lo[j] * P.inv_dz;
                 if (WANT_DT) { // the bottom cell's own coefficients; Dirichlet faces: half a cell away, face-state coefficients
@@ -603,7 +605,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 // -1/2 (a_lo + a_hi) (x_hi - x_lo)/dz /dz with the three constants (and Ksat) folded
                 // into the gradient's factor (see cgw above)
                 if (WATER) {
-                    gh = (h[j] - h_p[j]) * cgw[j];
+                    gh = head_difference(psi[j], psi_p[j], P.dz) * cgw[j];
                     Fw[j] = -(K_p[j] + K[j]) * gh;
                 }
                 if (HEAT) {
@@ -628,7 +630,6 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 ye_p[j] = ye[j];
             }
             K_p[j] = K[j];
-            h_p[j] = h[j];
             psi_p[j] = psi[j];
             T_p[j] = T[j];
             kap_p[j] = kap[j];
@@ -647,7 +648,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             FT K_f = FT(0), kap_f = FT(0);
             const FT K_c = K_p[j] * Ksc[j]; // the true conductivity of the boundary cell
             boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c[j], FACE_TOP, colj[j], vl[j], ti[j], T_p[j],
-                                                          K_c, psi_p[j], Fe[j], Fw[j], &K_f, &kap_f, vgf);
+                                                          K_c, -psi_p[j], Fe[j], Fw[j], &K_f, &kap_f, vgf);
             Fe[j] = Fe[j] * P.inv_dz;
             Fw[j] = Fw[j] * P.inv_dz;
             if (WANT_DT) { // the top cell's own coefficients, and the Dirichlet face's
@@ -704,7 +705,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 // level-segmented, a fused SSPRK33 step is three dependent launches of ~6 us each.
 // Here one workgroup owns one column and one thread one CELL, the state lives in
 // registers, and the whole loop over steps and stages runs inside one launch: per
-// stage every thread evaluates the closures of its cell, publishes K, h (T, kappa,
+// stage every thread evaluates the closures of its cell, publishes K, -psi (T, kappa,
 // rho_e_l K) in LDS, and forms the flux of the face below and the face above it from
 // its neighbours' values -- each interior face is evaluated by both adjacent threads
 // with the expression of rhs_kernel (lower cell first), so the step is bitwise the
@@ -714,6 +715,7 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
 // wavefront with one or two adjacent cells per lane and no workgroup barrier at all
 // (column_stepper_wave_kernel below).
 // exchange arrays per column / plane tiles of the initial fetch (the two share the dynamic LDS)
+constexpr int CS_FACE_WORDS = 8; // column_stepper_wave_kernel: 2 faces x (K, psi, kappa) of a Dirichlet face state, padded
 template <int MODEL> constexpr int cs_exchange_arrays() {
     return MODEL == MODEL_COUPLED ? 5 : 2;
 }
@@ -742,7 +744,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     const int slot = int(threadIdx.x) / tpc;
     const int cpb = int(blockDim.x) / tpc;
     const FT dt = dt_device ? *dt_device : dt_value;
-    // exchange arrays of this column: (K, h) for the water, (T, kappa) for the heat, rho_e_l K for
+    // exchange arrays of this column: (K, -psi) for the water, (T, kappa) for the heat, rho_e_l K for
     // both -- only what the model needs (LDS per workgroup sets how many workgroups a CU holds)
     constexpr int NARR = cs_exchange_arrays<MODEL>();
     FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * n;
@@ -803,7 +805,6 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
     FT y_re = HEAT ? fetched(2) : FT(0);
     const FT Ta = need_Taux ? (pf_T ? pf_T[ic] : fetched(3)) : FT(288);
     __syncthreads();
-    const FT z = P.zc[ic];
     FT nf_acc = FT(0);
     for (int64_t s = 0; s < nsteps; ++s) {
         FT u_vl = y_vl, u_re = y_re; // the stage state
@@ -816,18 +817,17 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 P.bc_value[1][0] = b[2];
                 P.bc_value[1][1] = b[3];
             }
-            FT T = Ta, kap = FT(0), K = FT(0), psi = FT(0), h = FT(0), E = FT(0), rcs = FT(1);
+            FT T = Ta, kap = FT(0), K = FT(0), psi = FT(0), E = FT(0), rcs = FT(1);
             if (HEAT) {
                 T = temperature_closure<FT, M, NOICE>(mm, P, c, u_vl, ti, u_re, rcs);
                 kap = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl, ti);
             }
             if (WATER) {
-                water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT>(mm, P, c, u_vl, ti, T, K, psi, nullptr, vgf);
-                h = psi + z;
+                water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT, true>(mm, P, c, u_vl, ti, T, K, psi, nullptr, vgf); // psi: -psi
                 if (HEAT) E = (P.rhocp_l * (T - P.T_ref)) * K; // rho_e_int_l * K (:364)
             }
             if (i < n) {
-                if (WATER) { sK[i] = K; sh[i] = h; }
+                if (WATER) { sK[i] = K; sh[i] = psi; }
                 if (HEAT) { sT[i] = T; sKap[i] = kap; }
                 if (HEAT && WATER) sE[i] = E;
             }
@@ -839,7 +839,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
             const bool at_bottom = (i == 0), at_top = (i == n - 1);
             if (i < n && (at_bottom || at_top)) {
                 boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, u_vl, ti,
-                                                              T, K * Ksc, psi, Fe_b, Fw_b, nullptr, nullptr, vgf);
+                                                              T, K * Ksc, -psi, Fe_b, Fw_b, nullptr, nullptr, vgf);
                 Fe_b = Fe_b * P.inv_dz;
                 Fw_b = Fw_b * P.inv_dz;
             }
@@ -850,7 +850,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 } else {
                     FT gh = FT(0);
                     if (WATER) { // (as rhs_kernel)
-                        gh = (h - sh[i - 1]) * cgw;
+                        gh = head_difference(psi, sh[i - 1], P.dz) * cgw;
                         Fw_lo = -(sK[i - 1] + K) * gh;
                     }
                     if (HEAT) {
@@ -861,7 +861,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 }
                 if (at_top) {
                     if (at_bottom) { // a one-cell column: the same thread owns both faces
-                        boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K * Ksc, psi, Fe_hi, Fw_hi, nullptr, nullptr, vgf);
+                        boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, u_vl, ti, T, K * Ksc, -psi, Fe_hi, Fw_hi, nullptr, nullptr, vgf);
                         Fe_hi = Fe_hi * P.inv_dz;
                         Fw_hi = Fw_hi * P.inv_dz;
                     } else {
@@ -871,7 +871,7 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
                 } else {
                     FT gh = FT(0);
                     if (WATER) {
-                        gh = (sh[i + 1] - h) * cgw;
+                        gh = head_difference(sh[i + 1], psi, P.dz) * cgw;
                         Fw_hi = -(K + sK[i + 1]) * gh;
                     }
                     if (HEAT) {
@@ -942,17 +942,20 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
     const int l = int(threadIdx.x) & 63;    // lane = CW adjacent cells
     const int cpb = int(blockDim.x) >> 6;
     const FT dt = dt_device ? *dt_device : dt_value;
-    // per column: the top cell of every lane -- (K, h), (T, kappa), rho_e_l K as the model needs --
+    // per column: the top cell of every lane -- (K, -psi), (T, kappa), rho_e_l K as the model needs --
     // and the flux(es) of the face below every lane's bottom cell; 64 words each
+    // (+ CS_FACE_WORDS per column: K, psi, kappa of the face state of a Dirichlet face, bottom and top)
     constexpr int NEX = cs_exchange_arrays<MODEL>();
     constexpr int NARR = NEX + cs_flux_arrays<MODEL>();
-    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * NARR * 64;
+    constexpr size_t COLW = size_t(NARR) * 64 + CS_FACE_WORDS;
+    FT* sK = reinterpret_cast<FT*>(s_dyn) + size_t(slot) * COLW;
     FT* sh = sK + 64;
     FT* sT = WATER ? sh + 64 : sK;
     FT* sKap = sT + 64;
     FT* sE = sKap + 64;
-    FT* sFw = reinterpret_cast<FT*>(s_dyn) + (size_t(slot) * NARR + NEX) * 64;
+    FT* sFw = sK + size_t(NEX) * 64;
     FT* sFe = WATER ? sFw + 64 : sFw;
+    FT* sFace = sK + size_t(NARR) * 64;
     const M mm(stage_math_tables<M>(P0.math_tab, s_tab));
     if (!M::uses_tables) __syncthreads();
     DevParams<FT> P = P0; // boundary values change per stage
@@ -990,7 +993,7 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
     if (HEAT) request(Y.v[2], 2);
     if (need_Taux && !pf_T) request(AUX.v[3], 3);
     __syncthreads();
-    FT y_vl[CW], y_re[CW], ti[CW], Ta[CW], z[CW];
+    FT y_vl[CW], y_re[CW], ti[CW], Ta[CW];
     bool act[CW]; // the cell exists (and the column does)
 #pragma unroll
     for (int q = 0; q < CW; ++q) {
@@ -1002,10 +1005,32 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
         ti[q] = NOICE ? FT(0) : (pf_ti ? pf_ti[ic] : (have ? tiles[tile_n + slot * n + ic] : FT(0))); // NOICE: the theta_i plane is known to be all zeros
         y_re[q] = (HEAT && have) ? tiles[2 * tile_n + slot * n + ic] : FT(0);
         Ta[q] = need_Taux ? (pf_T ? pf_T[ic] : (have ? tiles[3 * tile_n + slot * n + ic] : FT(288))) : FT(288);
-        z[q] = P.zc[ic];
     }
     __syncthreads(); // the tiles overlay other columns' exchange arrays
     const int lt = (n - 1) / CW, qt = (n - 1) - lt * CW; // lane and slot of the top cell
+    const bool at_bottom = (l == 0), at_top = (l == lt);
+    // Dirichlet faces: the closures of the FACE state -- a whole extra closure pass by one lane while
+    // its wave waits -- read the boundary value, the boundary cell's theta_i and (some models) its
+    // vartheta_l or T.  With constant boundary values and none of those moving (face_state_is_static)
+    // they are constants of the call: evaluated once here, kept in LDS, and a stage only assembles
+    // the two fluxes from them (boundary_fluxes_from) -- the same numbers as boundary_fluxes.
+    const bool hoist_b = !bcv && face_state_is_static<FT, MODEL, FACTORS>(P, FACE_BOTTOM);
+    const bool hoist_t = !bcv && face_state_is_static<FT, MODEL, FACTORS>(P, FACE_TOP);
+    auto hoist_face = [&](int face, int q_cell) {
+        FT bv = y_vl[0], bti = ti[0], bT = Ta[0];
+#pragma unroll
+        for (int q = 1; q < CW; ++q)
+            if (q == q_cell) { bv = y_vl[q]; bti = ti[q]; bT = Ta[q]; }
+        const FaceState<FT> fs = face_state<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, face, col, bv, bti, bT, vgf);
+        FT* dst = sFace + (face == FACE_BOTTOM ? 0 : 3);
+        dst[0] = fs.K;
+        dst[1] = fs.psi;
+        dst[2] = fs.kap;
+    };
+    if ((at_bottom && hoist_b) || (at_top && hoist_t && !at_bottom)) // (one divergent pass for both lanes)
+        hoist_face(at_bottom ? FACE_BOTTOM : FACE_TOP, at_bottom ? 0 : qt);
+    if (at_bottom && at_top && hoist_t) hoist_face(FACE_TOP, qt); // a column of <= CW cells
+    wave_sync();
     FT nf_acc = FT(0);
     for (int64_t s = 0; s < nsteps; ++s) {
         FT u_vl[CW], u_re[CW]; // the stage state
@@ -1023,31 +1048,29 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
                 P.bc_value[1][0] = b[2];
                 P.bc_value[1][1] = b[3];
             }
-            FT T[CW], kap[CW], K[CW], psi[CW], h[CW], E[CW];
+            FT T[CW], kap[CW], K[CW], psi[CW], E[CW];
 #pragma unroll
             for (int q = 0; q < CW; ++q) {
                 FT rcs = FT(1);
                 T[q] = Ta[q];
-                kap[q] = K[q] = psi[q] = h[q] = E[q] = FT(0);
+                kap[q] = K[q] = psi[q] = E[q] = FT(0);
                 if (HEAT) {
                     T[q] = temperature_closure<FT, M, NOICE>(mm, P, c, u_vl[q], ti[q], u_re[q], rcs);
                     kap[q] = kappa_closure<FT, M, NOICE>(mm, P, c, u_vl[q], ti[q]);
                 }
                 if (WATER) {
-                    water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT>(mm, P, c, u_vl[q], ti[q], T[q], K[q], psi[q], nullptr, vgf);
-                    h[q] = psi[q] + z[q];
+                    water_closures<FT, M, FACTORS, true, false, NOICE, RELK, HEAT, true>(mm, P, c, u_vl[q], ti[q], T[q], K[q], psi[q], nullptr, vgf); // psi: -psi
                     if (HEAT) E[q] = (P.rhocp_l * (T[q] - P.T_ref)) * K[q]; // rho_e_int_l * K (:364)
                 }
             }
             // the lane's top cell, for the lane above
-            if (WATER) { sK[l] = K[CW - 1]; sh[l] = h[CW - 1]; }
+            if (WATER) { sK[l] = K[CW - 1]; sh[l] = psi[CW - 1]; }
             if (HEAT) { sT[l] = T[CW - 1]; sKap[l] = kap[CW - 1]; }
             if (HEAT && WATER) sE[l] = E[CW - 1];
             wave_sync();
             // boundary faces: the lane with the bottom cell and the lane with the top cell go through
             // boundary_fluxes TOGETHER (one divergent pass, not two, when both faces need closures)
             FT Fw_b = FT(0), Fe_b = FT(0), Fw_t = FT(0), Fe_t = FT(0);
-            const bool at_bottom = (l == 0), at_top = (l == lt);
             if (at_bottom || at_top) {
                 // (the top cell's slot qt is uniform: a chain of selects over the unrolled slots)
                 FT bv = u_vl[0], bti = ti[0], bT = T[0], bK = K[0], bpsi = psi[0];
@@ -1056,21 +1079,30 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
                     for (int q = 1; q < CW; ++q)
                         if (q == qt) { bv = u_vl[q]; bti = ti[q]; bT = T[q]; bK = K[q]; bpsi = psi[q]; }
                 }
+                auto face_fluxes = [&](int face, bool hoisted, FT& fe, FT& fw) {
+                    FaceState<FT> fs;
+                    if (hoisted) {
+                        const FT* src = sFace + (face == FACE_BOTTOM ? 0 : 3);
+                        fs.K = src[0];
+                        fs.psi = src[1];
+                        fs.kap = src[2];
+                        fs.T = face_state_T<FT, MODEL>(P, face, col, bT);
+                    } else {
+                        fs = face_state<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, face, col, bv, bti, bT, vgf);
+                    }
+                    boundary_fluxes_from<FT, MODEL>(P, fs, face, col, bT, bK * Ksc, -bpsi, fe, fw);
+                    fe = fe * P.inv_dz;
+                    fw = fw * P.inv_dz;
+                };
                 FT fe, fw;
-                boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, at_bottom ? FACE_BOTTOM : FACE_TOP, col, bv, bti, bT,
-                                                              bK * Ksc, bpsi, fe, fw, nullptr, nullptr, vgf);
-                fe = fe * P.inv_dz;
-                fw = fw * P.inv_dz;
+                face_fluxes(at_bottom ? FACE_BOTTOM : FACE_TOP, at_bottom ? hoist_b : hoist_t, fe, fw);
                 if (at_bottom) { Fe_b = fe; Fw_b = fw; }
                 else { Fe_t = fe; Fw_t = fw; }
                 if (at_bottom && at_top) { // a column of <= CW cells: the same lane owns both faces
 #pragma unroll
                     for (int q = 0; q < CW; ++q)
                         if (q == qt) { bv = u_vl[q]; bti = ti[q]; bT = T[q]; bK = K[q]; bpsi = psi[q]; }
-                    boundary_fluxes<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, FACE_TOP, col, bv, bti, bT, bK * Ksc, bpsi, Fe_t, Fw_t,
-                                                                  nullptr, nullptr, vgf);
-                    Fe_t = Fe_t * P.inv_dz;
-                    Fw_t = Fw_t * P.inv_dz;
+                    face_fluxes(FACE_TOP, hoist_t, Fe_t, Fw_t);
                 }
             }
             // F[q]: the face below the lane's cell q; F[CW]: the face above its top cell
@@ -1083,7 +1115,7 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
             } else { // (as rhs_kernel: lower cell first)
                 FT gh = FT(0);
                 if (WATER) {
-                    gh = (h[0] - sh[l - 1]) * cgw;
+                    gh = head_difference(psi[0], sh[l - 1], P.dz) * cgw;
                     Fw[0] = -(sK[l - 1] + K[0]) * gh;
                 }
                 if (HEAT) {
@@ -1096,7 +1128,7 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
             for (int q = 1; q < CW; ++q) {
                 FT gh = FT(0);
                 if (WATER) {
-                    gh = (h[q] - h[q - 1]) * cgw;
+                    gh = head_difference(psi[q], psi[q - 1], P.dz) * cgw;
                     Fw[q] = -(K[q - 1] + K[q]) * gh;
                 }
                 if (HEAT) {
@@ -1501,11 +1533,10 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
     const int64_t lanes = (P.ncols + CFG::CPL - 1) / CFG::CPL;
     dim3 g = grid_for(lanes, block), b(block);
     if (CFG::SEG) g.y = (unsigned)((P.nlev + P.seg_len - 1) / P.seg_len);
-    // dynamic LDS: z_i, plus one word per thread for the mode-4 reduction
+    // dynamic LDS: one word per thread for the mode-4 reduction
     // (+ two level arrays for level-uniform prescribed fields of Ya where the kernel can take them)
     constexpr bool MAY_PROF = (MODEL == MODEL_HEAT) || (MODEL == MODEL_RICHARDS && FACTORS);
-    const unsigned dyn = (unsigned)((((size_t)P.nlev * sizeof(FT) + 15) & ~(size_t)15) +
-                                    (mode == 4 ? (((size_t)block * sizeof(float) + 15) & ~(size_t)15) : 0) +
+    const unsigned dyn = (unsigned)((mode == 4 ? (((size_t)block * sizeof(float) + 15) & ~(size_t)15) : 0) +
                                     (MAY_PROF ? 2 * (size_t)P.nlev * sizeof(FT) : 0));
     if constexpr (!M::is_production) { // MathLibm: tendency only (the other modes are never instantiated)
         hipLaunchKernelGGL((rhs_kernel<FT, MODEL, FACTORS, PERCOL, CFG, M, 0, false>), g, b, dyn, s, P, in, aux, base, out, dt, dt_dev);
@@ -1649,7 +1680,7 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
     const int tiles = cs_fetch_tiles(MODEL, noice && !factors, need_Taux);
     // dynamic LDS: the plane tiles of the initial fetch and the exchange arrays share it
     const int narr = cs_exchange_arrays<MODEL>() + (wave ? cs_flux_arrays<MODEL>() : 0);
-    const size_t ex_words = wave ? (size_t)narr * 64 : (size_t)narr * (size_t)P.nlev;
+    const size_t ex_words = wave ? (size_t)narr * 64 + CS_FACE_WORDS : (size_t)narr * (size_t)P.nlev;
     const size_t tile_words = (size_t)tiles * (size_t)P.nlev;
     const size_t dyn_col = (ex_words > tile_words ? ex_words : tile_words) * sizeof(FT);
     using M = MathFast<FT>;
