@@ -476,6 +476,29 @@ __device__ __forceinline__ FT temperature_closure(const M& mm, const DevParams<F
 // expensive part: a full water and/or kappa closure), boundary_fluxes_from assembles the two fluxes
 // from it.  The persistent steppers evaluate the first part once per call when nothing it reads
 // changes during the call (face_state_is_static).
+// kinds and values of one face's boundary conditions.  `face` may be a per-lane value (the steppers'
+// bottom and top lanes go through the boundary code together): selects between the two faces' uniform
+// entries, not an indexed read of the by-value parameter block (which would put it into scratch memory).
+template <typename FT>
+struct FaceBC {
+    int ke, kh; // kind of the energy / hydrology component
+    FT ve, vh;  // value (per-column array element where one is set)
+};
+template <typename FT>
+__device__ __forceinline__ FaceBC<FT> face_bc(const DevParams<FT>& P, int face, int64_t col) {
+    const bool b = (face == FACE_BOTTOM);
+    FaceBC<FT> r;
+    r.ke = b ? P.bc_kind[FACE_BOTTOM][COMP_ENERGY] : P.bc_kind[FACE_TOP][COMP_ENERGY];
+    r.kh = b ? P.bc_kind[FACE_BOTTOM][COMP_HYDROLOGY] : P.bc_kind[FACE_TOP][COMP_HYDROLOGY];
+    r.ve = b ? P.bc_value[FACE_BOTTOM][COMP_ENERGY] : P.bc_value[FACE_TOP][COMP_ENERGY];
+    r.vh = b ? P.bc_value[FACE_BOTTOM][COMP_HYDROLOGY] : P.bc_value[FACE_TOP][COMP_HYDROLOGY];
+    const FT* pe = b ? P.bc_pc[FACE_BOTTOM][COMP_ENERGY] : P.bc_pc[FACE_TOP][COMP_ENERGY];
+    const FT* ph = b ? P.bc_pc[FACE_BOTTOM][COMP_HYDROLOGY] : P.bc_pc[FACE_TOP][COMP_HYDROLOGY];
+    if (pe) r.ve = pe[col];
+    if (ph) r.vh = ph[col];
+    return r;
+}
+
 template <typename FT>
 struct FaceState {
     FT K, psi, kap, T; // K(face state), psi(face state), kappa(face state), T of the face state
@@ -487,11 +510,9 @@ __device__ __forceinline__ FaceState<FT> face_state(const M& mm, const DevParams
                                                     bool vgfast = false) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
-    const int ke = P.bc_kind[face][COMP_ENERGY];
-    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
-    FT ve = P.bc_value[face][COMP_ENERGY], vh = P.bc_value[face][COMP_HYDROLOGY];
-    if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
-    if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
+    const FaceBC<FT> bc = face_bc(P, face, col);
+    const int ke = bc.ke, kh = bc.kh;
+    const FT ve = bc.ve, vh = bc.vh;
     FaceState<FT> fs;
     fs.K = fs.psi = fs.kap = FT(0);
     FT vl_f = vl_c; // face := centre (:218-228)
@@ -512,8 +533,9 @@ template <typename FT, int MODEL, bool FACTORS>
 __device__ __forceinline__ bool face_state_is_static(const DevParams<FT>& P, int face) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
-    const int ke = P.bc_kind[face][COMP_ENERGY];
-    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
+    const bool bot = (face == FACE_BOTTOM);
+    const int ke = bot ? P.bc_kind[FACE_BOTTOM][COMP_ENERGY] : P.bc_kind[FACE_TOP][COMP_ENERGY];
+    const int kh = bot ? P.bc_kind[FACE_BOTTOM][COMP_HYDROLOGY] : P.bc_kind[FACE_TOP][COMP_HYDROLOGY];
     const bool needs_w = WATER && kh == BC_DIRICHLET, needs_k = HEAT && ke == BC_DIRICHLET;
     bool ok = true;
     if (needs_w && FACTORS && P.viscosity_kind && HEAT && ke != BC_DIRICHLET) ok = false; // T_f = T_c moves
@@ -524,8 +546,9 @@ __device__ __forceinline__ bool face_state_is_static(const DevParams<FT>& P, int
 // the T of the face state (the value face_state puts into FaceState::T)
 template <typename FT, int MODEL>
 __device__ __forceinline__ FT face_state_T(const DevParams<FT>& P, int face, int64_t col, FT T_c) {
-    if (MODEL == MODEL_RICHARDS || P.bc_kind[face][COMP_ENERGY] != BC_DIRICHLET) return T_c;
-    return P.bc_pc[face][COMP_ENERGY] ? P.bc_pc[face][COMP_ENERGY][col] : P.bc_value[face][COMP_ENERGY];
+    if (MODEL == MODEL_RICHARDS) return T_c;
+    const FaceBC<FT> bc = face_bc(P, face, col);
+    return bc.ke == BC_DIRICHLET ? bc.ve : T_c;
 }
 
 template <typename FT, int MODEL>
@@ -533,11 +556,9 @@ __device__ __forceinline__ void boundary_fluxes_from(const DevParams<FT>& P, con
                                                      int64_t col, FT T_c, FT K_c, FT psi_c, FT& f_e, FT& f_w) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
     constexpr bool HEAT = (MODEL != MODEL_RICHARDS);
-    const int ke = P.bc_kind[face][COMP_ENERGY];
-    const int kh = P.bc_kind[face][COMP_HYDROLOGY];
-    FT ve = P.bc_value[face][COMP_ENERGY], vh = P.bc_value[face][COMP_HYDROLOGY];
-    if (P.bc_pc[face][COMP_ENERGY]) ve = P.bc_pc[face][COMP_ENERGY][col];
-    if (P.bc_pc[face][COMP_HYDROLOGY]) vh = P.bc_pc[face][COMP_HYDROLOGY][col];
+    const FaceBC<FT> bc = face_bc(P, face, col);
+    const int ke = bc.ke, kh = bc.kh;
+    const FT ve = bc.ve, vh = bc.vh;
     const FT dzb = P.half_dz;
     const FT sgn = (face == FACE_BOTTOM) ? FT(-1) : FT(1);
     f_e = FT(0);
@@ -567,8 +588,11 @@ __device__ __forceinline__ void boundary_fluxes(const M& mm, const DevParams<FT>
                                                 FT& f_w, FT* K_face = nullptr,
                                                 FT* kappa_face = nullptr, bool vgfast = false) {
     const FaceState<FT> fs = face_state<FT, M, MODEL, FACTORS, NOICE>(mm, P, c, face, col, vl_c, ti_c, T_c, vgfast);
-    if (K_face && MODEL != MODEL_HEAT && P.bc_kind[face][COMP_HYDROLOGY] == BC_DIRICHLET) *K_face = fs.K;
-    if (kappa_face && MODEL != MODEL_RICHARDS && P.bc_kind[face][COMP_ENERGY] == BC_DIRICHLET) *kappa_face = fs.kap;
+    const bool bot = (face == FACE_BOTTOM);
+    const int kh = bot ? P.bc_kind[FACE_BOTTOM][COMP_HYDROLOGY] : P.bc_kind[FACE_TOP][COMP_HYDROLOGY];
+    const int ke = bot ? P.bc_kind[FACE_BOTTOM][COMP_ENERGY] : P.bc_kind[FACE_TOP][COMP_ENERGY];
+    if (K_face && MODEL != MODEL_HEAT && kh == BC_DIRICHLET) *K_face = fs.K;
+    if (kappa_face && MODEL != MODEL_RICHARDS && ke == BC_DIRICHLET) *kappa_face = fs.kap;
     boundary_fluxes_from<FT, MODEL>(P, fs, face, col, T_c, K_c, psi_c, f_e, f_w);
 }
 

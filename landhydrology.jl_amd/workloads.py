@@ -122,6 +122,30 @@ def make_case(name: str, ncols: Optional[int] = None, col_offset: int = 0, _nlev
     if name.endswith("_icesorted"):   # the family's case with ice-free columns first (ice_sorted_order)
         base = make_case(name[:-len("_icesorted")], ncols, col_offset, _nlev=_nlev)
         return reorder_columns(base, ice_sorted_order(base.ti))
+    # boundary-condition variants of a family (which closures a Dirichlet face state needs, and whether
+    # they are constants of a stepping call: face_state_is_static in lh_closures.hpp):
+    #   _hyddir  top face: the hydrology Dirichlet value stays, the energy component becomes a flux
+    #            (a viscosity factor then sees the moving T of the boundary cell)
+    #   _endir   top face: the energy Dirichlet value stays, the hydrology component becomes a flux
+    #            (kappa of the face state then sees the moving vartheta_l of the boundary cell)
+    #   _pcdir   every Dirichlet value becomes a per-column array
+    for suffix in ("_hyddir", "_endir", "_pcdir"):
+        if name.endswith(suffix):
+            import copy
+            case = make_case(name[:-len(suffix)], ncols, col_offset, _nlev=_nlev)
+            om = copy.deepcopy(case.om)
+            top_e, top_h = (M.FACE_TOP, M.COMP_ENERGY), (M.FACE_TOP, M.COMP_HYDROLOGY)
+            if suffix == "_hyddir" and top_e in om.bc:
+                om.bc[top_e] = (M.BC_FLUX, 0.05)
+            elif suffix == "_endir" and top_h in om.bc:
+                om.bc[top_h] = (M.BC_FLUX, -1e-8)
+            elif suffix == "_pcdir":
+                cols = np.arange(case.ncols) + col_offset
+                for k, (kind, v) in om.bc.items():
+                    if kind == M.BC_DIRICHLET:
+                        om.percol_bc[k] = v * (1.0 + 0.05 * (uhash(cols, 77 + 2 * k[0] + k[1], 1) - 0.5))
+            case.om, case.name = om, name
+            return case
     nlev_override = None
     mm_ = re.match(r"^(.*)_n(\d+)$", name)
     if mm_:

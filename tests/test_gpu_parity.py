@@ -30,7 +30,9 @@ CASES = ["c1_dirichlet_f64", "c2_richards_f64", "c2_richards_f32", "c4_richards_
          "c3_coupled_f32", "c3_coupled_f64", "c5_percol_f64", "heat_dirichlet_f64",
          "heat_dirichlet_f32", "mixed_factors_f64", "mixed_factors_f32", "mixed_smooth_f64", "mixed_smooth_f32",
          "richards_viscosity_f64",
-         "single_cell_f64"]
+         "single_cell_f64",
+         # boundary-condition variants: one Dirichlet component per face, per-column Dirichlet values
+         "mixed_smooth_f64_hyddir", "mixed_smooth_f32_endir", "mixed_smooth_f64_pcdir", "c1_dirichlet_f64_pcdir"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -106,7 +106,13 @@ TALL = ["c4_richards_f64_128", "c2_richards_f64_n97", "c2_richards_f64_n66", "c2
         "c2_richards_f64_n3", "mixed_smooth_f64_n2"]
 
 
-@pytest.mark.parametrize("name", CASES + ["single_cell_f64"] + TALL)
+# Dirichlet faces whose face-state closures are (not) constants of a call: the wave stepper evaluates
+# them once per call or once per stage (face_state_is_static), per-column boundary values included
+FACES = ["mixed_smooth_f64_hyddir", "mixed_smooth_f32_endir", "mixed_smooth_f64_pcdir", "c1_dirichlet_f64_pcdir",
+         "mixed_smooth_f64_n101_hyddir", "heat_dirichlet_f64_pcdir", "richards_viscosity_f64_pcdir"]
+
+
+@pytest.mark.parametrize("name", CASES + ["single_cell_f64"] + TALL + FACES)
 def test_persistent_column_stepper_is_bitwise_the_fused_stages(name):
     """Ensembles of few columns step inside ONE launch (workgroup = column, thread = cell,
     column_stepper_kernel).  Same closures, same face expressions, same stage updates as
