@@ -81,6 +81,9 @@ def parse():
 
 WORKLOADS = {
     # name -> (case name of workloads.make_case, algorithmic bytes per cell-update, dtype tag)
+    # BASELINE config 1 as an ensemble: the reference's own single 64-layer column with constant-head
+    # (Dirichlet) top and bottom faces, replicated --ncols times
+    "c1": ("c1_dirichlet_f64", 32.0, "f64"),
     "c2": ("c2_richards_f64", 32.0, "f64"),
     "c3": ("c3_coupled_f32", 24.0, "f32"),
     "c4": ("c4_richards_f64_128", 32.0, "f64"),

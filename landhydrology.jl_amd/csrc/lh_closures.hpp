@@ -559,13 +559,15 @@ __device__ __forceinline__ void boundary_fluxes_from(const DevParams<FT>& P, con
     const FaceBC<FT> bc = face_bc(P, face, col);
     const int ke = bc.ke, kh = bc.kh;
     const FT ve = bc.ve, vh = bc.vh;
-    const FT dzb = P.half_dz;
+    // (x / (dz/2) as x * (2 (1/dz)): the reciprocal is a constant of the grid, and a Float64 division is
+    // a dozen instructions the steppers' boundary lanes would issue every stage with their waves waiting)
+    const FT dzb = P.half_dz, inv_dzb = FT(2) * P.inv_dz;
     const FT sgn = (face == FACE_BOTTOM) ? FT(-1) : FT(1);
     f_e = FT(0);
     f_w = FT(0);
     if (HEAT) {
         if (ke == BC_FLUX) f_e = ve;
-        else if (ke == BC_DIRICHLET) f_e = sgn * (-fs.kap * (fs.T - T_c) / dzb); // :416-444
+        else if (ke == BC_DIRICHLET) f_e = sgn * ((-fs.kap * (fs.T - T_c)) * inv_dzb); // :416-444
     }
     if (WATER) {
         if (kh == BC_FLUX) {
@@ -574,9 +576,9 @@ __device__ __forceinline__ void boundary_fluxes_from(const DevParams<FT>& P, con
             f_w = -K_c;
         } else if (kh == BC_DIRICHLET) { // :371-401
             if (face == FACE_BOTTOM && P.consistent_bottom_sign)
-                f_w = fs.K * (fs.psi - psi_c - dzb) / dzb;
+                f_w = (fs.K * (fs.psi - psi_c - dzb)) * inv_dzb;
             else
-                f_w = sgn * (-fs.K * (fs.psi - psi_c + dzb) / dzb);
+                f_w = sgn * ((-fs.K * (fs.psi - psi_c + dzb)) * inv_dzb);
         }
     }
 }

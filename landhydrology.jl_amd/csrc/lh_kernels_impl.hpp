@@ -929,8 +929,17 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
 // operations of one wave execute in order) -- bitwise the fused stages.  CW = 1: columns of <= 64
 // levels; CW = 2: the 128-level configurations, which the thread-per-cell form runs with two waves
 // per column, two workgroup barriers per stage and every interior face evaluated twice.
+// waves per SIMD the compiler is asked to leave room for (wave_stepper_columns picks the workgroup size
+// from the register count it ends up with): the Float64 Richards instantiations sit within a register
+// or two of the 80-register step (6 waves), so they are held to it
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int CW, bool NOICE>
+constexpr int cs_wave_min_waves() {
+    if (!M::uses_tables || MODEL != MODEL_RICHARDS || PERCOL) return 4; // (1024 threads = 4 waves per SIMD)
+    if (CW == 1) return 6; // (the ice-free kernel needs 61 of its own accord; held to 64 it runs 4 % slower)
+    return (NOICE && !FACTORS) ? 6 : 4;
+}
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int CW, bool NOICE = false, bool VGF = true>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, (cs_wave_min_waves<FT, MODEL, FACTORS, PERCOL, M, CW, NOICE>()))
 column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<FT> AUX, const FT dt_value,
                            const FT* __restrict__ dt_device, const int64_t nsteps, const FT* __restrict__ bcv) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
