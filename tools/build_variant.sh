@@ -9,7 +9,7 @@ src=${SRC:-$root/landhydrology.jl_amd/csrc}
 out=$root/landhydrology.jl_amd/lib/variants
 tmp=$(mktemp -d /tmp/lh_variant.XXXXXX)
 mkdir -p "$out"
-flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function"
+flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -Wno-unused-function"
 for f in "$src"/*.hip; do
     /opt/rocm/bin/hipcc $flags "$@" -c "$f" -o "$tmp/$(basename "$f" .hip).o" &
 done
