@@ -6,7 +6,7 @@ TAG=${1:-r}
 OUT=gpurun_out/${TAG}_bench_all.jsonl
 : > $OUT
 run() { python bench.py --no-cpu-baseline "$@" >> $OUT 2>> gpurun_out/${TAG}_bench_all.err || echo "{\"failed\": \"$*\"}" >> $OUT; }
-for w in c2 c3 c4 c5 f3v64 f3v64p f3c32 f3c64 f3c32s f3c64s; do run --workload $w; done
+for w in c1 c2 c3 c4 c5 f3v64 f3v64p f3c32 f3c64 f3c32s f3c64s; do run --workload $w; done
 run --workload c2 --no-known-zero --no-stepper
 run --workload c3 --no-known-zero --no-stepper
 run --workload c3 --placement-tune --no-stepper

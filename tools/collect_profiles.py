@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workloads = sys.argv[1], sys.argv[2:]
-rnd = {"r2": "round2", "r3": "round3"}.get(tag, tag)
+rnd = {"r2": "round2", "r3": "round3", "r3f": "round3"}.get(tag, tag)
 out_json = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 try:
     table = json.load(open(out_json))
