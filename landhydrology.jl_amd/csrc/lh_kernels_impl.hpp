@@ -296,6 +296,20 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             if (FACTORS) { vr(P.gamma); vr(P.T_ref_visc); vr(P.Omega); }
         }
     }
+#ifndef LH_F64_FACTORS_PARTIAL_PIN
+#define LH_F64_FACTORS_PARTIAL_PIN 3
+#endif
+    // The Float64 tendency with conductivity factors stays at 4 waves per SIMD (128 registers) with the
+    // uniforms in the SGPR file and its spills (see rhs_waves_per_simd) -- but the three constants every
+    // cell's T and rho_e_l K use fit beside them: 52 -> fewer v_readlane per two cells, f3c64 0.560 ->
+    // 0.546 ms (same-process A/B; five or eight pinned: no further gain)
+    if constexpr (LH_F64_FACTORS_PARTIAL_PIN > 0 && heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() && MODE == 0 &&
+                  FACTORS && !PERCOL) {
+        auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
+        vr(P.rho_c_ds); vr(P.rhocp_l); vr(P.T_ref);
+        if (LH_F64_FACTORS_PARTIAL_PIN >= 5) { vr(P.rhocp_i); vr(P.rho_i); }
+        if (LH_F64_FACTORS_PARTIAL_PIN >= 8) { vr(P.LH_f0); vr(P.gamma); vr(P.Omega); }
+    }
     constexpr int CPL = CFG::CPL, PF = CFG::PF;
     constexpr bool NT = CFG::NT;
     constexpr bool TEND = (MODE == 0 || MODE == 4); // writes a tendency (not a stage state)
