@@ -303,7 +303,11 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // uniforms in the SGPR file and its spills (see rhs_waves_per_simd) -- but the three constants every
     // cell's T and rho_e_l K use fit beside them: 52 -> fewer v_readlane per two cells, f3c64 0.560 ->
     // 0.546 ms (same-process A/B; five or eight pinned: no further gain)
-    if constexpr (LH_F64_FACTORS_PARTIAL_PIN > 0 && heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() && MODE == 0 &&
+#ifndef LH_F64_FACTORS_PARTIAL_PIN_STAGES
+#define LH_F64_FACTORS_PARTIAL_PIN_STAGES 0 // (the fused stages carry more state: the same pinning costs them a wave, 0.64 -> 0.81 ms)
+#endif
+    if constexpr (LH_F64_FACTORS_PARTIAL_PIN > 0 && heat_vgpr_constants<FT, MODEL, FACTORS, PERCOL, M, NOICE>() &&
+                  (MODE == 0 || (LH_F64_FACTORS_PARTIAL_PIN_STAGES && MODE != 4)) &&
                   FACTORS && !PERCOL) {
         auto vr = [](FT& x) { asm volatile("" : "+v"(x)); };
         vr(P.rho_c_ds); vr(P.rhocp_l); vr(P.T_ref);
