@@ -561,7 +561,9 @@ def main():
             s1.record()
             torch.cuda.synchronize()
             ms = s0.elapsed_time(s1) / (ns * calls)
-            return {"ms_per_step": ms, "steps_per_call": ns, "cell_updates_per_s": 3 * cells / (ms * 1e-3)}
+            eng = L.lh_step_engine(ctx, ns, 0)
+            return {"ms_per_step": ms, "steps_per_call": ns, "cell_updates_per_s": 3 * cells / (ms * 1e-3),
+                    "engine": {F.LH_ENGINE_FUSED_STAGES: "fused stages", F.LH_ENGINE_COLUMN_STEPPER: "column stepper"}.get(eng, eng)}
         try:    # extra fields only: never at the price of the headline line
             out["ssprk33"] = time_steps(30, 2)            # the library's own choice of engine
             F.check(L.lh_set_tuning(ctx, b"persist=0"), ctx)

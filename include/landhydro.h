@@ -285,6 +285,15 @@ int lh_diagnostics(lh_ctx*, const lh_state* Y, const lh_state* Ya, lh_state* out
 int lh_step_ssprk33(lh_ctx*, lh_state* Y, const lh_state* Ya, double t, double dt,
                     int64_t nsteps, const double* bc_stage_values);
 
+/* Which engine lh_step_ssprk33 runs a call of nsteps steps with (no counterpart in the reference;
+ * for logs, benches and tests -- results do not depend on it: the engines are bitwise equal):
+ * LH_ENGINE_FUSED_STAGES = three fused-stage launches per step (rhs_kernel MODE 1-3),
+ * LH_ENGINE_COLUMN_STEPPER = ONE launch of the persistent column stepper for the whole call (state in
+ * registers).  per_stage_boundary_values: the call would pass bc_stage_values != NULL.
+ * Returns the engine (>= 0) or a negative LH_E* code. */
+enum { LH_ENGINE_FUSED_STAGES = 0, LH_ENGINE_COLUMN_STEPPER = 1 };
+int lh_step_engine(const lh_ctx*, int64_t nsteps, int32_t per_stage_boundary_values);
+
 /* One stage of that step (OrdinaryDiffEq SSPRK33, Shu-Osher form), for hosts that must refresh
  * Ya between the stage evaluations: the reference's rhs! calls update_aux_en!/update_aux_hydr!
  * with the STAGE time at every evaluation (right_hand_side.jl:37-42, 54-81), so a prescribed

@@ -25,6 +25,7 @@ LH_VAR_VARTHETA_L, LH_VAR_THETA_I, LH_VAR_RHOE_INT, LH_VAR_T = 0, 1, 2, 3
 LH_DIAG_K, LH_DIAG_PSI, LH_DIAG_KAPPA, LH_DIAG_T = 0, 1, 2, 3
 LH_MATH_FAST, LH_MATH_LIBM = 0, 1
 LH_PLACE_MOVE_INPUT = 1
+LH_ENGINE_FUSED_STAGES, LH_ENGINE_COLUMN_STEPPER = 0, 1
 LH_COMM_ID_BYTES = 128
 LH_PC = dict(vg_n=0, vg_alpha=1, vg_theta_r=2, vg_Ksat=3, nu=4, S_s=5)
 LH_OK, LH_EINVAL, LH_ENODEVICE, LH_ENOMEM, LH_EMODEL, LH_ESTATE = 0, -1, -2, -3, -4, -5
@@ -96,6 +97,7 @@ SIGNATURES = {
     "lh_boundary_fluxes": (C.c_int, [_P, _P, _P, C.c_double, C.c_int32, _DP, _DP]),
     "lh_diagnostics": (C.c_int, [_P, _P, _P, _P]),
     "lh_step_ssprk33": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, _DP]),
+    "lh_step_engine": (C.c_int, [_P, C.c_int64, C.c_int32]),
     "lh_ssprk33_stage": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, _DP]),
     "lh_step_ssprk33_device_dt": (C.c_int, [_P, _P, _P, C.c_double, _P, _DP]),
     "lh_step_ssprk33_adaptive": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_int64, _P, _P]),

@@ -1526,6 +1526,11 @@ int lh_diagnostics(lh_ctx* c, const lh_state* Y, const lh_state* Ya, lh_state* o
     return LH_OK;
 }
 
+int lh_step_engine(const lh_ctx* c, int64_t nsteps, int32_t per_stage_boundary_values) {
+    if (!c || nsteps < 0) return LH_EINVAL;
+    return use_column_stepper(c, nsteps, per_stage_boundary_values != 0) ? LH_ENGINE_COLUMN_STEPPER : LH_ENGINE_FUSED_STAGES;
+}
+
 int lh_step_ssprk33(lh_ctx* c, lh_state* Y, const lh_state* Ya, double t, double dt, int64_t nsteps,
                     const double* bcv) {
     (void)t;

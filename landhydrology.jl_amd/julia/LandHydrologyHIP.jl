@@ -40,7 +40,8 @@ using CLIMAParameters.SubgridScale: von_karman_const
 import LandHydrology.SoilInterface: make_rhs
 
 export HIPBackend, ColumnEnsemble, upload, download, device_rhs!, step_ssprk33!, stable_dt,
-    rhs_stable_dt!, step_ssprk33_device_dt!, block_range, comm_unique_id, attach_comm!, detach_comm!
+    rhs_stable_dt!, step_ssprk33_device_dt!, block_range, comm_unique_id, attach_comm!, detach_comm!,
+    step_engine
 
 const lib = get(ENV, "LANDHYDRO_HIP_LIB", "liblandhydro_hip.so")
 
@@ -365,10 +366,27 @@ function step_ssprk33!(ens::ColumnEnsemble{FT}, Y::DeviceState, Ya, t, dt, nstep
         vals[:, :, k, s] = bc_stage_values(ens, t + (s - 1) * dt + off)
     end
     set_bcs!(ens, t)
+    # boundary values that do not change over the call go in through set_bcs! alone (NULL here): the
+    # library then evaluates the closures of a Dirichlet face state once per call, not once per stage
+    base = bc_stage_values(ens, t)
+    constant = all(vals[:, :, k, s] == base for k in 1:3, s in 1:nsteps)
     check(ens.ctx, ccall((:lh_step_ssprk33, lib), Cint,
                          (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Float64}),
-                         ens.ctx, Y.handle, ya, t, dt, nsteps, vals))
+                         ens.ctx, Y.handle, ya, t, dt, nsteps, constant ? C_NULL : vals))
     return Y
+end
+
+"""
+    step_engine(ens, nsteps; per_stage_boundary_values = false)
+
+`:column_stepper` or `:fused_stages`: the engine `lh_step_ssprk33` runs such a call with (the
+results do not depend on it).
+"""
+function step_engine(ens::ColumnEnsemble, nsteps::Integer; per_stage_boundary_values::Bool = false)
+    e = ccall((:lh_step_engine, lib), Cint, (Ptr{Cvoid}, Int64, Int32), ens.ctx, Int64(nsteps),
+              Int32(per_stage_boundary_values))
+    e < 0 && check(ens.ctx, e)
+    return e == 1 ? :column_stepper : :fused_stages
 end
 
 "rhs! plus this rank's stable-step bound (one FT value at the device pointer `dt_dev`) in one launch"

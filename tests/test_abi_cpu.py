@@ -53,6 +53,8 @@ def test_create_rejects_bad_arguments(pkg):
         rc = L.lh_create(C.byref(ctx), C.byref(cfg))
         assert rc == F.LH_EINVAL and not ctx.value
         assert L.lh_last_error(None)
+    # calls that only read a context refuse a NULL one (no device is touched)
+    assert L.lh_step_engine(None, 10, 0) == F.LH_EINVAL
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(pkg):

@@ -139,3 +139,29 @@ def test_persistent_column_stepper_is_bitwise_the_fused_stages(name):
         assert res[0][1] == res[1][1]
         for k in res[0][0]:
             np.testing.assert_array_equal(res[0][0][k], res[1][0][k], err_msg=f"{name} bcv={use_bcv} {k}")
+
+
+def test_engine_choice_for_large_ensembles():
+    """lh_step_engine: large ensembles step in the persistent column stepper from 3 steps per call on;
+    with a Dirichlet face only where the face state's closures are constants of the call (constant
+    boundary values, nothing else they read moves); the Float64 coupled model with conductivity factors
+    stays with the fused stages; LH_TUNE persist= overrides."""
+    def engine(name, nsteps, per_stage, tune=b"", ncols=40000):
+        case = pc.make_case(name, ncols=ncols)
+        with pc.GpuModel(case) as g:
+            g.F.check(g.L.lh_set_tuning(g.ctx, tune), g.ctx)
+            return g.L.lh_step_engine(g.ctx, nsteps, per_stage)
+    F = pc._pkg()._ffi
+    ST, FU = F.LH_ENGINE_COLUMN_STEPPER, F.LH_ENGINE_FUSED_STAGES
+    assert engine("c2_richards_f64", 30, 0) == ST              # flux boundaries
+    assert engine("c2_richards_f64", 2, 0) == FU               # too few steps to pay the tile I/O
+    assert engine("c2_richards_f64", 2, 0, ncols=100) == ST    # small ensembles: always
+    assert engine("c1_dirichlet_f64", 30, 0) == ST             # Dirichlet faces, constant values
+    assert engine("c1_dirichlet_f64", 30, 1) == FU             # ... per-stage values: closures every stage
+    assert engine("richards_viscosity_f64", 30, 0) == ST       # T prescribed: static
+    assert engine("mixed_smooth_f32", 30, 0) == ST
+    assert engine("mixed_smooth_f32_hyddir", 30, 0) == FU      # viscosity sees the moving T of the boundary cell
+    assert engine("mixed_smooth_f32_endir", 30, 0) == FU       # kappa of the face state sees the moving vartheta_l
+    assert engine("mixed_smooth_f64", 30, 0) == FU             # Float64 closures bound both engines
+    assert engine("c2_richards_f64", 30, 0, tune=b"persist=0") == FU
+    assert engine("mixed_smooth_f64", 30, 1, tune=b"persist=2") == ST
