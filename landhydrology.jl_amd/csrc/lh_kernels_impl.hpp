@@ -65,8 +65,9 @@ constexpr bool heat_vgpr_constants() {
     return sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && M::is_production && !NOICE;
 }
 
-template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false>
+template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int PF, int MODE, bool NOICE = false, int CPL = 1>
 constexpr int rhs_waves_per_simd() {
+    if (sizeof(FT) == 4 && CPL >= 4) return 4; // (tuning builds: four Float32 columns per lane, 16-byte accesses)
     // Float64 heat kernels with conductivity factors: 127 VGPRs (4 waves/SIMD, 512-thread workgroups)
     // with the uniform constants left to the SGPR file and its spills beats 156 VGPRs with the
     // constants VGPR-resident at 3 waves (f3c64 tendency 0.530 vs 0.554 ms); the step-bound launch
@@ -274,8 +275,8 @@ __device__ __forceinline__ bool finite(FT x) {
 // water closures put the exponents of their 2^(.) in place by integer addition (water_closures_log); the
 // host decides (DevParams::vg_fast_all), clay-like ensembles run the VGF = false instantiation.
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename CFG, typename M, int MODE, bool NOICE = false, bool VGF = true>
-__global__ void __launch_bounds__((rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()),
-                                  (rhs_min_waves<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE>()>()))
+__global__ void __launch_bounds__((rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE, CFG::CPL>()>()),
+                                  (rhs_min_waves<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MODE, NOICE, CFG::CPL>()>()))
 rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, const Planes<FT> BASE,
            const Planes<FT> OUT, const FT dt_value, const FT* __restrict__ dt_device) {
     constexpr bool WATER = (MODEL != MODEL_HEAT);
@@ -1553,7 +1554,7 @@ static void launch_rhs_mode(const DevParams<FT>& P, const Planes<FT>& in, const 
     // workgroup size: the kernel's own (see rhs_max_threads) unless LH_TUNE block= asks for less
     const int mode_k = M::is_production ? mode : 0;
     int kmax = 256;
-#define LH_KMAX(MD) case MD: kmax = rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MD, NOICE && M::is_production>()>(); break;
+#define LH_KMAX(MD) case MD: kmax = rhs_max_threads<M, rhs_waves_per_simd<FT, MODEL, FACTORS, PERCOL, M, CFG::PF, MD, NOICE && M::is_production, CFG::CPL>()>(); break;
     switch (mode_k) { LH_KMAX(0) LH_KMAX(1) LH_KMAX(2) LH_KMAX(3) LH_KMAX(4) LH_KMAX(5) }
 #undef LH_KMAX
     const int block = (block_req > 0 && block_req <= kmax) ? block_req : kmax;
@@ -1600,7 +1601,7 @@ static void launch_rhs_model(const DevParams<FT>& P, const Planes<FT>& in, const
         return;                                                                                    \
     }
         LH_TRY(1, 1, true) LH_TRY(1, 2, true) LH_TRY(1, 3, true) LH_TRY(1, 4, true)
-        LH_TRY(2, 1, true) LH_TRY(2, 2, true) LH_TRY(1, 1, false) LH_TRY(1, 2, false)
+        LH_TRY(2, 1, true) LH_TRY(2, 2, true) LH_TRY(1, 1, false) LH_TRY(1, 2, false) LH_TRY(4, 1, true) LH_TRY(4, 2, true)
 #undef LH_TRY
     }
 #endif
