@@ -53,8 +53,13 @@ def test_create_rejects_bad_arguments(pkg):
         rc = L.lh_create(C.byref(ctx), C.byref(cfg))
         assert rc == F.LH_EINVAL and not ctx.value
         assert L.lh_last_error(None)
-    # calls that only read a context refuse a NULL one (no device is touched)
+    # every entry point refuses a NULL context before it touches a device
     assert L.lh_step_engine(None, 10, 0) == F.LH_EINVAL
+    assert L.lh_upload_profile(None, None, F.LH_VAR_VARTHETA_L, None) == F.LH_EINVAL
+    assert L.lh_state_release_ptr(None, None, F.LH_VAR_VARTHETA_L) == F.LH_EINVAL
+    assert L.lh_boundary_fluxes(None, None, None, 0.0, 0, None, None) == F.LH_EINVAL
+    assert L.lh_rhs(None, 0.0, None, None, None) == F.LH_EINVAL
+    assert L.lh_step_ssprk33(None, None, None, 0.0, 1.0, 1, None) == F.LH_EINVAL
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(pkg):
