@@ -117,9 +117,21 @@ def run(nseeds=4, verbose=True):
                                 print(f"    {k}: worst at {i}: got {g[i]!r} want {w[i]!r} tol {tol[k][i]:.3g} vl={case.vl[i]!r} "
                                       f"ti={case.ti[i]!r} percol={ {q: float(v[i[0]]) for q, v in case.om.percol.items()} }")
                         try:
-                            d_got = pc.run_gpu_rhs(case)
                             d_want = pc.run_oracle_rhs(case)
+                            # an input the REFERENCE answers with NaN (liquid below theta_r next to ice under the
+                            # impedance factor: 0/0) must come back as NaN in the same cells, with the flag raised
+                            nonfinite_expected = any(not np.all(np.isfinite(v)) for v in d_want.values())
+                            with pc.GpuModel(case) as g_:
+                                Y_, Ya_ = g_.prognostic_and_aux()
+                                dY_ = g_.state(0)
+                                g_.rhs(Y_, Ya_, dY_)
+                                d_got = g_.tendencies(dY_)
+                                assert (g_.status() != 0) == nonfinite_expected, "non-finite flag disagrees with the oracle"
                             ok_cols = ~ill.any(axis=1)     # (columns with a noise-valued K are not compared)
+                            for k in d_want:
+                                bad_w = ~np.isfinite(d_want[k])
+                                assert np.array_equal(bad_w, ~np.isfinite(d_got[k])), f"{k}: non-finite cells differ from the oracle's"
+                                ok_cols &= ~bad_w.any(axis=1)
                             tolt = pc.tendency_tolerance(case, cw)
                             for k in d_want:
                                 if k == "ti":
