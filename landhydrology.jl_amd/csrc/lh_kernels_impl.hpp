@@ -951,9 +951,25 @@ column_stepper_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Planes<F
 // waves per SIMD the compiler is asked to leave room for (wave_stepper_columns picks the workgroup size
 // from the register count it ends up with): the Float64 Richards instantiations sit within a register
 // or two of the 80-register step (6 waves), so they are held to it
+// A value every lane of the wave holds identically (the per-column constants of the one column a wave of
+// the wave stepper owns), moved to the scalar register file word by word: the vector registers it
+// occupied are free again, and it is used as a uniform operand from then on.
+template <typename T>
+__device__ __forceinline__ T wave_uniform(const T& x) {
+    static_assert(sizeof(T) % 4 == 0, "32-bit words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &x, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) w[k] = __builtin_amdgcn_readfirstlane(w[k]);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+
 template <typename FT, int MODEL, bool FACTORS, bool PERCOL, typename M, int CW, bool NOICE>
 constexpr int cs_wave_min_waves() {
-    if (!M::uses_tables || MODEL != MODEL_RICHARDS || PERCOL) return 4; // (1024 threads = 4 waves per SIMD)
+    if (!M::uses_tables || MODEL != MODEL_RICHARDS) return 4; // (1024 threads = 4 waves per SIMD)
+    // (per-column parameters are scalar registers here, wave_uniform: the same budgets hold)
     if (CW == 1) return 6; // (the ice-free kernel needs 61 of its own accord; held to 64 it runs 4 % slower)
     return (NOICE && !FACTORS) ? 6 : 4;
 }
@@ -996,6 +1012,9 @@ column_stepper_wave_kernel(const DevParams<FT> P0, const Planes<FT> Y, const Pla
     const int64_t col = col_raw < P.ncols ? col_raw : P.ncols - 1; // spare slots shadow the last column
     ColC<FT> c = make_colc<FT, M>(P, col, PERCOL);
     if (WATER && !NOICE) finish_colc<FT, M>(mm, c);
+    // one wave = one column: its per-column constants are uniform (rhs_kernel, one LANE per column,
+    // has to keep them in vector registers)
+    if constexpr (PERCOL) c = wave_uniform(c);
     constexpr bool vgf = VGF && M::uses_tables;
     constexpr bool RELK = M::is_production; // fluxes in tendency units, K without Ksat: as rhs_kernel, to the letter
     const FT cgT = P.cg2;
