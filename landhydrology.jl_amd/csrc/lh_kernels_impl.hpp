@@ -1686,10 +1686,10 @@ void launch_rhs_for_model(const DevParams<FT>& P, const Planes<FT>& in, const Pl
 // count that keeps most waves resident under the instantiation's register count and the LDS of a
 // CU (48 KiB of math tables per Float64 workgroup + the exchange arrays of its columns): 12 for
 // Float64 Richards without ice (63 / 77 VGPRs, 6 waves per SIMD), 8 for the per-column-parameter
-// and ice kernels (94+ VGPRs: a second 768-thread workgroup would not fit), 4 for Float32.
-// Small ensembles take 4 to spread over the CUs.
+// and ice kernels (94+ VGPRs: a second 768-thread workgroup would not fit), 4 for Float32 (8 for
+// short calls).  Small ensembles take 4 to spread over the CUs.
 template <auto Kernel>
-unsigned wave_stepper_columns(int64_t ncols, size_t dyn_col) {
+unsigned wave_stepper_columns(int64_t ncols, size_t dyn_col, int64_t nsteps) {
     static const hipFuncAttributes attr = [] {
         hipFuncAttributes a{};
         if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(Kernel)) != hipSuccess) a.numRegs = 0;
@@ -1704,7 +1704,10 @@ unsigned wave_stepper_columns(int64_t ncols, size_t dyn_col) {
         const unsigned by_lds = unsigned((size_t(160) << 10) / (lds ? lds : 1));
         const unsigned by_regs = waves_cu / c;
         const unsigned resident = c * (by_lds < by_regs ? by_lds : by_regs);
-        if (resident > best_resident) best = c, best_resident = resident;
+        // equal residency (Float32: no tables): 4 columns step fastest, 8 halve the row pieces of the
+        // tile I/O -- T(n) = 1.26 + 0.422 n against 0.89 + 0.439 n ms on C3 (tools/stepper_call_cost.py):
+        // the wider workgroup wins calls of up to 20 steps
+        if (resident > best_resident || (resident == best_resident && c == 8u && nsteps <= 20)) best = c, best_resident = resident;
     }
     return best;
 }
@@ -1736,9 +1739,9 @@ void launch_column_stepper_for_model(const DevParams<FT>& P, const Planes<FT>& Y
 #define LH_CS_GO(F, PC, NI, VG)                                                                                                        \
     do {                                                                                                                               \
         if (wave && cw == 1) {                                                                                                         \
-            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>>(P.ncols, dyn_col);                  \
+            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 1, NI, VG>>(P.ncols, dyn_col, nsteps);                  \
         } else if (wave) {                                                                                                             \
-            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>>(P.ncols, dyn_col);                  \
+            cpb = wave_stepper_columns<column_stepper_wave_kernel<FT, MODEL, F, PC, M, 2, NI, VG>>(P.ncols, dyn_col, nsteps);                  \
         }                                                                                                                              \
         if (P.cs_cpb > 0 && (unsigned)P.cs_cpb * tpc <= 1024u) cpb = (unsigned)P.cs_cpb;                                               \
         const dim3 g((unsigned)((P.ncols + cpb - 1) / cpb)), b(tpc * cpb);                                                             \

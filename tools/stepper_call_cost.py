@@ -17,7 +17,7 @@ for wl in (sys.argv[1:] or ["c2", "c3", "c4"]):
     case = bench.build_case(wl, int(os.environ.get("NCOLS", "1000000")), 0)
     with pc.GpuModel(case) as g:
         F, L, ctx = g.F, g.L, g.ctx
-        F.check(L.lh_set_tuning(ctx, b"persist=2"), ctx)
+        F.check(L.lh_set_tuning(ctx, ("persist=2" + os.environ.get("TUNE_EXTRA", "")).encode()), ctx)
         Y, Ya = g.prognostic_and_aux()
         ns_list = [1, 2, 3, 5, 10, 30, 100]
         ts = []
