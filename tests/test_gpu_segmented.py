@@ -163,5 +163,7 @@ def test_engine_choice_for_large_ensembles():
     assert engine("mixed_smooth_f32_hyddir", 30, 0) == FU      # viscosity sees the moving T of the boundary cell
     assert engine("mixed_smooth_f32_endir", 30, 0) == FU       # kappa of the face state sees the moving vartheta_l
     assert engine("mixed_smooth_f64", 30, 0) == FU             # Float64 closures bound both engines
+    assert engine("heat_dirichlet_f64", 30, 0) == ST           # heat only: the prescribed water fields are static
+    assert engine("c5_percol_f64", 30, 0) == ST                # per-column parameters and flux values
     assert engine("c2_richards_f64", 30, 0, tune=b"persist=0") == FU
     assert engine("mixed_smooth_f64", 30, 1, tune=b"persist=2") == ST
