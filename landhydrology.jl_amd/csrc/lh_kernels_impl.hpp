@@ -22,6 +22,9 @@ namespace lh {
 #ifndef LH_RHS_WAVES_PER_SIMD
 #define LH_RHS_WAVES_PER_SIMD 8
 #endif
+#ifndef LH_RHS_F64_WAVES
+#define LH_RHS_F64_WAVES 6
+#endif
 
 // waves/SIMD the Float32 coupled tendency + step-bound launch is compiled for (86 VGPRs unconstrained)
 #ifndef LH_F32C_DT_WAVES
@@ -85,7 +88,12 @@ constexpr int rhs_waves_per_simd() {
     if (M::is_production && FACTORS && sizeof(FT) == 8 && MODEL != MODEL_RICHARDS && !PERCOL &&
         (MODE == 0 || (LH_F64_FACTORS_STAGE_WAVES4 && MODE != 4))) return LH_F64_FACTORS_TEND_WAVES;
     if (!M::is_production || FACTORS) return 1;
-    if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? LH_PERCOL_DT_WAVES : LH_RHS_WAVES_PER_SIMD; // 62 VGPRs (72 with the dt bound)
+    // Float64 Richards without ice fits 64 VGPRs (8 waves) in every mode, but asked for only 6 waves (<= 80 VGPRs,
+    // 512-thread workgroups, 3 per CU) the max-ILP scheduler uses the room: tendency -1 %, with the step bound -2 %,
+    // C5 -1.6 %, the Dirichlet ensemble C1 -4 %, fused stages equal (round 3, same-process A/B).  Float32 keeps 8
+    // (its fused stages lose 5 % at 6).
+    if (MODEL == MODEL_RICHARDS && NOICE && sizeof(FT) == 8 && !PERCOL) return LH_RHS_F64_WAVES;
+    if (MODEL == MODEL_RICHARDS && NOICE && PERCOL) return MODE == 4 ? LH_PERCOL_DT_WAVES : (sizeof(FT) == 8 ? LH_RHS_F64_WAVES : LH_RHS_WAVES_PER_SIMD); // 62 VGPRs (72 with the dt bound)
     if (PERCOL) return 1;
     if (MODEL == MODEL_RICHARDS && NOICE) return LH_RHS_WAVES_PER_SIMD; // no ice ring: fits 64 VGPRs in every mode
     if (MODEL == MODEL_RICHARDS) return PF > 1 ? 7 : LH_RHS_WAVES_PER_SIMD; // a deeper ring costs registers
