@@ -167,3 +167,27 @@ def test_engine_choice_for_large_ensembles():
     assert engine("c5_percol_f64", 30, 0) == ST                # per-column parameters and flux values
     assert engine("c2_richards_f64", 30, 0, tune=b"persist=0") == FU
     assert engine("mixed_smooth_f64", 30, 1, tune=b"persist=2") == ST
+
+
+def test_column_height_sweep_is_bitwise_in_both_engines():
+    """Every column height class of the steppers -- 1..5 cells, around 32 / 64 / 96 / 128 levels (one
+    wave with one or two cells per lane, ragged top lanes, whole lanes empty), beyond 128 (one thread
+    per cell) -- with flux, Dirichlet and per-column Dirichlet boundaries: five steps are the same bits
+    as the fused stages."""
+    bad = []
+    for fam in ("mixed_smooth_f64", "mixed_smooth_f32", "c2_richards_f64", "mixed_smooth_f64_pcdir"):
+        for n in (1, 2, 3, 4, 5, 17, 31, 32, 33, 63, 64, 65, 66, 95, 96, 97, 127, 128, 129, 130, 160):
+            name = f"{fam[:-6]}_n{n}_pcdir" if fam.endswith("_pcdir") else f"{fam}_n{n}"
+            case = pc.make_case(name, ncols=37)
+            res = []
+            for tune in (b"persist=0,seg=-1", b"persist=2"):
+                with pc.GpuModel(case) as g:
+                    g.F.check(g.L.lh_set_tuning(g.ctx, tune), g.ctx)
+                    Y, Ya = g.prognostic_and_aux()
+                    g.F.check(g.L.lh_step_ssprk33(g.ctx, Y, Ya, 0.0, 0.5, 5, None), g.ctx)
+                    res.append((_fields(g, Y, case), g.status()))
+            same = res[0][1] == res[1][1] and all(np.array_equal(res[0][0][k], res[1][0][k], equal_nan=True)
+                                                  for k in res[0][0])
+            if not same:
+                bad.append(name)
+    assert not bad, bad
