@@ -75,7 +75,11 @@ def assert_state_close(case, got, want, tight):
 @pytest.mark.parametrize("name,nsteps", [("c2_richards_f64", 40), ("c4_richards_f64_128", 20),
                                          ("c3_coupled_f64", 30), ("c5_percol_f64", 25),
                                          ("mixed_smooth_f64", 30), ("c1_dirichlet_f64", 60),
-                                         ("richards_viscosity_f64", 30)])
+                                         ("richards_viscosity_f64", 30),
+                                         # one Dirichlet component per face / per-column Dirichlet values: the stepper
+                                         # evaluates those face states once per stage / once per call
+                                         ("mixed_smooth_f64_hyddir", 30), ("mixed_smooth_f64_pcdir", 30),
+                                         ("c1_dirichlet_f64_pcdir", 60)])
 def test_theta_zt_matches_oracle_f64(name, nsteps):
     case = pc.make_case(name, ncols=None if name != "c1_dirichlet_f64" else 3)
     dt = stable_dt(case)
