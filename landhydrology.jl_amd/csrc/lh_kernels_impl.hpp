@@ -721,7 +721,10 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
             const FT best = (FT(2) * dt * P.dz * P.dz) / FT(dmax); // dmax = twice the diffusivity
             U b;
             __builtin_memcpy(&b, &best, sizeof(FT));
-            atomicMin(reinterpret_cast<U*>(P.dt_out), b);
+            // (most waves' bound is above the minimum already there: a plain read first -- the atomic only
+            // when it would change the word; a stale read can only cause a redundant atomic)
+            U* word = reinterpret_cast<U*>(P.dt_out);
+            if (b < __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMin(word, b);
         }
     }
 }
