@@ -1424,7 +1424,7 @@ stable_dt_kernel(const DevParams<FT> P, const Planes<FT> IN, const Planes<FT> AU
     if ((threadIdx.x & 63) == 0 && best < FT(INFINITY)) {
         U b;
         __builtin_memcpy(&b, &best, sizeof(FT));
-        atomicMin(out_bits, b);
+        if (b < __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMin(out_bits, b); // (as rhs_kernel MODE 4: a read first)
     }
 }
 
