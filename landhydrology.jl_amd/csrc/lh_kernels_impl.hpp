@@ -337,6 +337,8 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
     // past the last column leave the neutral 0 there
     float* s_red = reinterpret_cast<float*>(s_dyn);
     if (WANT_DT) s_red[threadIdx.x] = 0.0f;
+    __shared__ unsigned s_waves_done; // MODE 4: waves of this workgroup that have left their maximum in s_red
+    if (WANT_DT && threadIdx.x == 0) s_waves_done = 0u;
     // level-uniform prescribed fields of Ya (DevParams::aux_prof), staged behind the reduction
     // words: T for the Richards viscosity factor, vartheta_l and theta_i for the heat-only model
     constexpr bool MAY_PROF = (MODEL == MODEL_HEAT) || (MODEL == MODEL_RICHARDS && FACTORS);
@@ -717,14 +719,25 @@ rhs_kernel(const DevParams<FT> P0, const Planes<FT> IN, const Planes<FT> AUX, co
                 seg[l] = dmax;
             }
         }
-        if (l == 0 && dmax > 0.0f) {
-            const FT best = (FT(2) * dt * P.dz * P.dz) / FT(dmax); // dmax = twice the diffusivity
-            U b;
-            __builtin_memcpy(&b, &best, sizeof(FT));
-            // (most waves' bound is above the minimum already there: a plain read first -- the atomic only
-            // when it would change the word; a stale read can only cause a redundant atomic)
-            U* word = reinterpret_cast<U*>(P.dt_out);
-            if (b < __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMin(word, b);
+        // One candidate per WORKGROUP: the last of its waves to get here (an LDS counter; no barrier, nobody waits)
+        // folds the others' maxima in -- seg[0] of every wave, written before that wave's count, in order.
+        if (l == 0) {
+            const int64_t first_lane = int64_t(blk) * blockDim.x;             // lanes (of CPL columns) before this workgroup
+            const int64_t lanes_left = (P.ncols + CPL - 1) / CPL - first_lane;  // > 0: the grid covers the columns
+            const unsigned nwaves = blockDim.x >> 6;
+            const unsigned nw = lanes_left >= int64_t(blockDim.x) ? nwaves : unsigned((lanes_left + 63) >> 6); // waves not gone at the top
+            if (atomicAdd(&s_waves_done, 1u) == nw - 1u) {
+                for (unsigned w = 0; w < nwaves; ++w) dmax = max_nonneg(dmax, s_red[w << 6]);
+                if (dmax > 0.0f) {
+                    const FT best = (FT(2) * dt * P.dz * P.dz) / FT(dmax); // dmax = twice the diffusivity
+                    U b;
+                    __builtin_memcpy(&b, &best, sizeof(FT));
+                    // (most bounds are above the minimum already there: a plain read first -- the atomic only
+                    // when it would change the word; a stale read can only cause a redundant atomic)
+                    U* word = reinterpret_cast<U*>(P.dt_out);
+                    if (b < __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMin(word, b);
+                }
+            }
         }
     }
 }
